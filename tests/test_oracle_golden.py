@@ -1,0 +1,155 @@
+"""Pin the CPU oracle (oracle/) against golden vectors produced by the reference itself."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _golden import GoldenCase, case_names, rel_err
+from oracle import rwnn_oracle as O
+from oracle import rwnn_torch_port as P
+
+CASES = case_names()
+# float32 reference vs float64 restatement: the reference's own rounding is ~1e-6 of the tensor scale
+TOL_F64_VS_REF = 2e-5
+
+
+def test_golden_cases_present():
+    assert len(CASES) >= 10
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_integer_structure_bit_exact(name):
+    c = GoldenCase(name)
+    crow, col, val = O.coo_to_csr(c["coo_indices"], c["coo_values"], c.n_nodes)
+    assert np.array_equal(crow, c["csr_crow"])
+    assert np.array_equal(col, c["csr_col"])
+    assert np.array_equal(val.view(np.uint32), c["csr_val"].view(np.uint32))
+    g, counts = O.segment_counts(c["graph_indicator"])
+    assert g == c["k"].shape[0]
+    assert np.array_equal(counts, c["counts"])
+
+
+def _x0(c, dtype=np.float64):
+    w = c.params["fc.weight"].astype(dtype)
+    b = c.params["fc.bias"].astype(dtype)
+    return 1.0 / (1.0 + np.exp(-(c["features"].astype(dtype) @ w.T + b)))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_numpy_forward_matches_reference(name):
+    c = GoldenCase(name)
+    csr = O.coo_to_csr(c["coo_indices"], c["coo_values"], c.n_nodes)
+    k = O.rw_kernel_forward(csr, _x0(c), c.params["adj_hidden"], c.params["features_hidden"],
+                            c["graph_indicator"], c.hp["max_step"], c.hp["normalize"])
+    assert k.shape == c["k"].shape
+    assert rel_err(k, c["k"]) < TOL_F64_VS_REF
+    k2 = O.rw_kernel_gram(csr, _x0(c), c.params["adj_hidden"], c.params["features_hidden"],
+                          c["graph_indicator"], c.hp["max_step"], c.hp["normalize"])
+    assert rel_err(k2, k) < 1e-11
+
+
+def _torch_port_grads(c, dtype):
+    adj, feats, gi, y = c.torch_inputs(dtype=dtype)
+    params = P.cast_params(c.torch_state(), dtype, requires_grad=True)
+    feats = feats.clone().requires_grad_(True)
+    bn_stats = None
+    if not c.train:
+        bn_stats = (torch.from_numpy(c.params["bn.running_mean"]).to(dtype),
+                    torch.from_numpy(c.params["bn.running_var"]).to(dtype))
+    out, k = P.forward(params, adj, feats, gi, c.hp["max_step"], c.hp["normalize"],
+                       c.hp["dropout"], c.train, bn_stats)
+    k.retain_grad()
+    loss = F.nll_loss(out, y)
+    loss.backward()
+    grads = {n: (p.grad.numpy() if p.grad is not None else None) for n, p in params.items()}
+    grads["features"] = feats.grad.numpy()
+    return out.detach().numpy(), k.detach().numpy(), float(loss.detach()), grads, k.grad.numpy()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_torch_port_matches_reference(name):
+    c = GoldenCase(name)
+    out, k, loss, grads, _ = _torch_port_grads(c, torch.float64)
+    assert rel_err(k, c["k"]) < TOL_F64_VS_REF
+    assert rel_err(out, c["out"]) < 1e-4
+    assert abs(loss - float(c["loss"])) < 1e-4 * max(1.0, abs(float(c["loss"])))
+    # End-to-end gradients pass through train-mode batch-norm over as few as 3 graphs, which
+    # amplifies the reference's own float32 rounding (its gradients are up to 3.5e-2 away from
+    # the float64 truth on "powerlawish_d32_step4"); eval-mode cases are well conditioned.
+    tol = 5e-2 if c.train else 1e-5
+    for n, ref in c.grads.items():
+        assert grads[n] is not None, n
+        assert rel_err(grads[n], ref) < tol, n
+    if c.hp["max_step"] == 1:
+        assert "adj_hidden" not in c.grads and grads["adj_hidden"] is None
+    # float32 port: same operators as the reference, so it agrees to rounding
+    out32, k32, _, _, _ = _torch_port_grads(c, torch.float32)
+    assert rel_err(k32, c["k"]) < 1e-6
+    assert rel_err(out32, c["out"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_numpy_backward_matches_reference_given_dk(name):
+    """Layer-level VJP: feed the reference's own dL/dK to the float64 restatement and compare
+    with the reference's float32 parameter gradients.  No batch-norm in between, so the only
+    difference is the reference's float32 rounding (measured <= 2e-4 of each tensor's scale)."""
+    c = GoldenCase(name)
+    csr = O.coo_to_csr(c["coo_indices"], c["coo_values"], c.n_nodes)
+    x0 = _x0(c)
+    d_x0, d_adj, d_feat = O.rw_kernel_backward(csr, x0, c.params["adj_hidden"], c.params["features_hidden"],
+                                               c["graph_indicator"], c.hp["max_step"], c["dk"], c.hp["normalize"])
+    d_pre = d_x0 * x0 * (1 - x0)
+    tol = 5e-4
+    assert rel_err(d_feat, c.grads["features_hidden"]) < tol
+    assert rel_err(d_pre @ c.params["fc.weight"].astype(np.float64), c.grads["features"]) < tol
+    assert rel_err(d_pre.sum(0), c.grads["fc.bias"]) < tol
+    assert rel_err(d_pre.T @ c["features"].astype(np.float64), c.grads["fc.weight"]) < tol
+    if c.hp["max_step"] > 1:
+        assert rel_err(d_adj, c.grads["adj_hidden"]) < tol
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_numpy_backward_matches_autograd(name):
+    """The analytic VJP of the layer equals autograd through the operator-for-operator port."""
+    c = GoldenCase(name)
+    _, _, _, grads, dk = _torch_port_grads(c, torch.float64)
+    csr = O.coo_to_csr(c["coo_indices"], c["coo_values"], c.n_nodes)
+    x0 = _x0(c)
+    d_x0, d_adj, d_feat = O.rw_kernel_backward(csr, x0, c.params["adj_hidden"], c.params["features_hidden"],
+                                               c["graph_indicator"], c.hp["max_step"], dk, c.hp["normalize"])
+    assert rel_err(d_feat, grads["features_hidden"]) < 1e-7
+    if c.hp["max_step"] > 1:
+        assert rel_err(d_adj, grads["adj_hidden"]) < 1e-7
+    # chain d_x0 through sigmoid + linear and compare with d loss / d features
+    d_pre = d_x0 * x0 * (1 - x0)
+    d_features = d_pre @ c.params["fc.weight"].astype(np.float64)
+    assert rel_err(d_features, grads["features"]) < 1e-7
+    assert rel_err(d_pre.sum(0), grads["fc.bias"]) < 1e-7
+
+
+def test_segment_counts_rejects_gaps():
+    with pytest.raises(IndexError):
+        O.segment_counts(np.array([0, 0, 2, 2]))
+    with pytest.raises(IndexError):
+        O.segment_counts(np.array([1, 1, 2]))
+
+
+def test_philox_known_answers():
+    """Random123 known-answer vectors for Philox4x32-10."""
+    r = O.philox4x32_10(0, 0, 0, 0, 0, 0)
+    assert [int(v) for v in r] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    r = O.philox4x32_10(0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff)
+    assert [int(v) for v in r] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    r = O.philox4x32_10(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0)
+    assert [int(v) for v in r] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_dropout_mask_statistics_and_replay():
+    keep = O.dropout_keep(seed=1234, offset=5, n_nodes=400, h=6, s=5, max_step=2, drop_p=0.2)
+    assert keep.shape == (2, 6, 5, 400)
+    frac = keep.mean()
+    assert abs(frac - 0.8) < 0.01
+    keep2 = O.dropout_keep(seed=1234, offset=6, n_nodes=400, h=6, s=5, max_step=2, drop_p=0.2)
+    assert (keep != keep2).mean() > 0.2
+    assert O.dropout_keep(1, 0, 10, 2, 3, 2, 0.0).all()
+    assert not O.dropout_keep(1, 0, 10, 2, 3, 2, 1.0).any()
