@@ -117,14 +117,14 @@ def test_numpy_backward_matches_autograd(name):
     x0 = _x0(c)
     d_x0, d_adj, d_feat = O.rw_kernel_backward(csr, x0, c.params["adj_hidden"], c.params["features_hidden"],
                                                c["graph_indicator"], c.hp["max_step"], dk, c.hp["normalize"])
-    assert rel_err(d_feat, grads["features_hidden"]) < 1e-7
+    assert rel_err(d_feat, grads["features_hidden"]) < 1e-6
     if c.hp["max_step"] > 1:
-        assert rel_err(d_adj, grads["adj_hidden"]) < 1e-7
+        assert rel_err(d_adj, grads["adj_hidden"]) < 1e-6
     # chain d_x0 through sigmoid + linear and compare with d loss / d features
     d_pre = d_x0 * x0 * (1 - x0)
     d_features = d_pre @ c.params["fc.weight"].astype(np.float64)
-    assert rel_err(d_features, grads["features"]) < 1e-7
-    assert rel_err(d_pre.sum(0), grads["fc.bias"]) < 1e-7
+    assert rel_err(d_features, grads["features"]) < 1e-6
+    assert rel_err(d_pre.sum(0), grads["fc.bias"]) < 1e-6
 
 
 def test_segment_counts_rejects_gaps():
