@@ -1,0 +1,11 @@
+"""gnn_amd -- MI355X-native random-walk-kernel layer (drop-in ``RW_NN``).
+
+Only what the hot path needs: HIP kernels + C ABI (``csrc/``, ``librwk.so``), the graph-structure
+cache, the autograd function, the ``nn.Module`` that mirrors the reference's interface, and the
+graph-sharded data-parallel helpers.
+"""
+from .model import RW_NN
+from .structure import GraphStructure, clear_structure_cache, get_structure
+from .function import rw_kernel_layer
+
+__all__ = ["RW_NN", "GraphStructure", "get_structure", "clear_structure_cache", "rw_kernel_layer"]

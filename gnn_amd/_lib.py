@@ -1,0 +1,79 @@
+"""ctypes binding of ``librwk.so`` (the C ABI declared in ``include/rwk.h``).
+
+There is no fallback: if the shared library is missing or a call fails, an exception is
+raised.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C gnn_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librwk.so")
+
+_P = c_void_p          # every device pointer travels as void*
+_I64 = c_int64
+
+#: name -> (restype, argtypes); kept in one table so the tests can check it against rwk.h
+SIGNATURES = {
+    "rwk_version": (c_int, []),
+    "rwk_error_string": (ctypes.c_char_p, [c_int]),
+    "rwk_coo_inspect": (c_int, [_P, _P, _I64, _I64, _P, _P]),
+    "rwk_csr_from_sorted_coo": (c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
+    "rwk_csr_count_asymmetric": (c_int, [_P, _P, _P, _I64, _P, _P]),
+    "rwk_indicator_inspect": (c_int, [_P, _I64, _P, _P]),
+    "rwk_segments_build": (c_int, [_P, _I64, _I64, _P, _P, _P, _P, _P, _P]),
+    "rwk_spmm_csr": (c_int, [_P, _P, _P, _I64, _I64, _P, _P, c_int, c_int32, _P, _I64, c_int32, _P]),
+    "rwk_hidden_forward": (c_int, [_P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P]),
+    "rwk_hidden_backward": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P]),
+    "rwk_fused_n_streams": (_I64, [_I64, _I64]),
+    "rwk_fused_k_partials_size": (_I64, [_I64, _I64, _I64, _I64, _I64]),
+    "rwk_fused_dz_partials_count": (_I64, [_I64, _I64, _I64, _I64, _I64, _I64]),
+    "rwk_fused_forward": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_float, _P, _P, _P]),
+    "rwk_fused_reduce": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, c_float, c_int, _P, _P]),
+    "rwk_fused_backward": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_float, c_int,
+                                   _P, _P, _P, _P]),
+    "rwk_dropout_mask": (c_int, [_P, _I64, _I64, _I64, _I64, c_float, _P, _P]),
+}
+
+_lib = None
+
+
+class RwkError(RuntimeError):
+    pass
+
+
+def load():
+    """Load ``librwk.so`` once and attach the prototypes.  Raises ``ImportError`` when absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built "
+            "(run `make -C gnn_amd/csrc` or `__graft_entry__.build()`); there is no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().rwk_error_string(code).decode()
+        raise RwkError(f"{what} failed: {msg} (code {code})")
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream(device):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

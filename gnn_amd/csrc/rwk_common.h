@@ -1,0 +1,110 @@
+// Shared device/host helpers for librwk (gfx950 only: 64-lane wavefronts, DPP, LDS).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rwk.h"
+
+#define RWK_WAVE 64
+
+#define RWK_REQUIRE_PTR(p) \
+    do {                   \
+        if ((p) == nullptr) return RWK_E_NULL; \
+    } while (0)
+
+#define RWK_LAUNCH_CHECK()                       \
+    do {                                         \
+        hipError_t e__ = hipGetLastError();      \
+        if (e__ != hipSuccess) return (int)e__;  \
+    } while (0)
+
+static inline int64_t rwk_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3").
+// ---------------------------------------------------------------------------------------
+struct RwkPhilox4 {
+    uint32_t x, y, z, w;
+};
+
+__host__ __device__ static inline RwkPhilox4 rwk_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
+                                                               uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return RwkPhilox4{c0, c1, c2, c3};
+}
+
+// Dropout keep-mask specification (shared by forward, backward, the mask dump and the oracle):
+//   one Philox stream per (node n, hidden graph h); element (step i, hidden node s) is sample
+//   e = s*L + i of that stream; sample e is byte (e % 15) of call (e / 15), where a call is
+//   philox4x32_10(counter = {n, h, call, offset_lo}, key = {seed_lo, seed_hi ^ offset_hi}) and byte j
+//   is bits [8*(j&3), 8*(j&3)+8) of output word j>>2.  Byte 15 of the call breaks ties:
+//   keep <=> b < T0 || (b == T0 && byte15 < T1), with T0 = floor(q*256), T1 = floor((q*256-T0)*256),
+//   q = 1 - p: the keep probability is q rounded down to a multiple of 2^-16.
+struct RwkDropCfg {
+    uint32_t t0;      // 0..256
+    uint32_t t1;      // 0..255
+    uint32_t seed_lo, key_hi, off_lo;
+};
+
+static inline void rwk_drop_thresholds(float drop_p, uint32_t *t0, uint32_t *t1) {
+    double q = 1.0 - (double)drop_p;
+    if (q < 0.0) q = 0.0;
+    if (q > 1.0) q = 1.0;
+    double a = q * 256.0;
+    uint32_t a0 = (uint32_t)a;
+    if (a0 > 256u) a0 = 256u;
+    double rem = (a - (double)a0) * 256.0;
+    uint32_t a1 = (uint32_t)rem;
+    if (a1 > 255u) a1 = 255u;
+    *t0 = a0;
+    *t1 = a1;
+}
+
+// 15 keep bits (bit j <-> byte j) of one call.
+__device__ static inline uint32_t rwk_keep_bits15(const RwkDropCfg &cfg, uint32_t n, uint32_t h, uint32_t call) {
+    const RwkPhilox4 r = rwk_philox4x32_10(n, h, call, cfg.off_lo, cfg.seed_lo, cfg.key_hi);
+    const uint32_t tie = (r.w >> 24) < cfg.t1 ? 1u : 0u;
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+    uint32_t bits = 0;
+#pragma unroll
+    for (int j = 0; j < 15; ++j) {
+        const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        const uint32_t k = (b < cfg.t0) ? 1u : ((b == cfg.t0) ? tie : 0u);
+        bits |= k << j;
+    }
+    return bits;
+}
+
+// ---------------------------------------------------------------------------------------
+// Sum over aligned groups of `width` consecutive lanes (width a power of two <= 64); every
+// lane of the group receives the total.  Fixed butterfly order => bitwise reproducible.
+// Lane distances 1 and 2 use quad-permute DPP; 4 and 8 use the half-row / row mirror DPP modes
+// (after the quad steps every quad is uniform, so a mirror pairs each quad with its partner);
+// 16 and 32 go through a cross-row permute.
+// ---------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ static inline float rwk_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+
+__device__ static inline float rwk_group_sum(float v, int width) {
+    if (width >= 2) v += rwk_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+    if (width >= 4) v += rwk_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+    if (width >= 8) v += rwk_dpp<0x141>(v);  // row_half_mirror: lane i <-> 7-i within 8 lanes
+    if (width >= 16) v += rwk_dpp<0x140>(v); // row_mirror:      lane i <-> 15-i within 16 lanes
+    if (width >= 32) v += __shfl_xor(v, 16, 64);
+    if (width >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}

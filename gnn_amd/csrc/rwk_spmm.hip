@@ -1,0 +1,136 @@
+// CSR SpMM  y = A x (+ y)  for narrow dense operands (d = 1..64 floats per row).
+//
+// One "group" of VEC*R lanes owns one output row: VEC lanes cover the d floats of the row as
+// float4 chunks (VEC = ceil(d/4)), R lanes split the row's stored entries round-robin and are
+// summed with a fixed butterfly at the end, so the result does not depend on scheduling.
+// R is chosen by the caller from the degree histogram: R = 1 (row per lane group, the right
+// shape for molecular / protein graphs of degree 2..8), larger R for dense rows, and rows above
+// `long_threshold` are taken out of the packed pass and given a whole wavefront each.
+//
+// HBM traffic per call (the figure the roofline uses): nnz*(4+4) + (n+1)*4 + 2*n*d*4 bytes.
+#include "rwk_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// VEC: float4 chunks per row (d padded to 4*VEC); ALIGNED: d == 4*VEC so rows are 16-byte aligned.
+template <int VEC, bool ALIGNED>
+__global__ void __launch_bounds__(kBlock)
+spmm_csr_kernel(const int32_t *__restrict__ crow, const int32_t *__restrict__ col,
+                const float *__restrict__ val, int n_rows_or_list, int d, const float *__restrict__ x,
+                float *__restrict__ y, int accumulate, int r_lanes, const int32_t *__restrict__ row_list,
+                int skip_above) {
+    const int group_lanes = VEC * r_lanes;              // power of two, <= 64
+    const long long gtid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const int group = (int)(gtid / group_lanes);
+    const int q = (int)(gtid % group_lanes);
+    const int sub = q % VEC;                            // which float4 of the row
+    const int r = q / VEC;                              // which share of the entries
+    const bool active = group < n_rows_or_list;
+    int row = 0, beg = 0, end = 0;
+    if (active) {
+        row = row_list ? row_list[group] : group;
+        beg = crow[row];
+        end = crow[row + 1];
+    }
+    const bool skipped = active && !row_list && skip_above > 0 && (end - beg) > skip_above;
+    if (skipped) end = beg;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = beg + r; j < end; j += r_lanes) {
+        const int c = col[j];
+        const float v = val[j];
+        float4 xv;
+        if (ALIGNED) {
+            xv = *reinterpret_cast<const float4 *>(x + (size_t)c * d + 4 * sub);
+        } else {
+            const float *xr = x + (size_t)c * d;
+            const int b = 4 * sub;
+            xv.x = b + 0 < d ? xr[b + 0] : 0.f;
+            xv.y = b + 1 < d ? xr[b + 1] : 0.f;
+            xv.z = b + 2 < d ? xr[b + 2] : 0.f;
+            xv.w = b + 3 < d ? xr[b + 3] : 0.f;
+        }
+        acc.x = fmaf(v, xv.x, acc.x);
+        acc.y = fmaf(v, xv.y, acc.y);
+        acc.z = fmaf(v, xv.z, acc.z);
+        acc.w = fmaf(v, xv.w, acc.w);
+    }
+    // sum the R shares: lanes q and q ^ (VEC*k) hold the same float4 chunk
+    for (int off = VEC; off < group_lanes; off <<= 1) {
+        acc.x += __shfl_xor(acc.x, off, 64);
+        acc.y += __shfl_xor(acc.y, off, 64);
+        acc.z += __shfl_xor(acc.z, off, 64);
+        acc.w += __shfl_xor(acc.w, off, 64);
+    }
+    if (!active || skipped || r != 0) return;
+    float *yr = y + (size_t)row * d;
+    const int b = 4 * sub;
+    if (ALIGNED) {
+        float4 *yp = reinterpret_cast<float4 *>(yr + b);
+        if (accumulate) {
+            const float4 o = *yp;
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+        *yp = acc;
+    } else {
+        const float a[4] = {acc.x, acc.y, acc.z, acc.w};
+        for (int k = 0; k < 4; ++k)
+            if (b + k < d) yr[b + k] = accumulate ? yr[b + k] + a[k] : a[k];
+    }
+}
+
+template <int VEC>
+int launch(const int32_t *crow, const int32_t *col, const float *val, int64_t n, int64_t d, const float *x,
+           float *y, int accumulate, int r_lanes, const int32_t *long_rows, int64_t n_long,
+           int32_t long_threshold, hipStream_t stream) {
+    const bool aligned = (d == 4 * VEC) && ((((uintptr_t)x | (uintptr_t)y) & 15u) == 0);
+    if (r_lanes * VEC > 64) r_lanes = 64 / VEC;
+    const int skip = (long_rows && n_long > 0) ? long_threshold : 0;
+    {
+        const int64_t threads = n * VEC * r_lanes;
+        const dim3 grid((unsigned)rwk_ceil_div(threads, kBlock));
+        if (aligned)
+            hipLaunchKernelGGL((spmm_csr_kernel<VEC, true>), grid, dim3(kBlock), 0, stream, crow, col, val, (int)n,
+                               (int)d, x, y, accumulate, r_lanes, (const int32_t *)nullptr, skip);
+        else
+            hipLaunchKernelGGL((spmm_csr_kernel<VEC, false>), grid, dim3(kBlock), 0, stream, crow, col, val, (int)n,
+                               (int)d, x, y, accumulate, r_lanes, (const int32_t *)nullptr, skip);
+        RWK_LAUNCH_CHECK();
+    }
+    if (skip > 0) {
+        const int rl = 64 / VEC;                       // a whole wavefront per long row
+        const int64_t threads = n_long * 64;
+        const dim3 grid((unsigned)rwk_ceil_div(threads, kBlock));
+        if (aligned)
+            hipLaunchKernelGGL((spmm_csr_kernel<VEC, true>), grid, dim3(kBlock), 0, stream, crow, col, val,
+                               (int)n_long, (int)d, x, y, accumulate, rl, long_rows, 0);
+        else
+            hipLaunchKernelGGL((spmm_csr_kernel<VEC, false>), grid, dim3(kBlock), 0, stream, crow, col, val,
+                               (int)n_long, (int)d, x, y, accumulate, rl, long_rows, 0);
+        RWK_LAUNCH_CHECK();
+    }
+    return RWK_OK;
+}
+
+}  // namespace
+
+extern "C" int rwk_spmm_csr(const int32_t *crow, const int32_t *col, const float *val, int64_t n, int64_t d,
+                            const float *x, float *y, int accumulate, int32_t row_lanes,
+                            const int32_t *long_rows, int64_t n_long, int32_t long_threshold,
+                            rwk_stream_t stream_) {
+    RWK_REQUIRE_PTR(crow);
+    RWK_REQUIRE_PTR(x);
+    RWK_REQUIRE_PTR(y);
+    if (n <= 0 || n >= 0x7FFFFFFFll || d <= 0 || n_long < 0 || n_long > n) return RWK_E_SIZE;
+    if (d > 64) return RWK_E_UNSUPPORTED;
+    if (row_lanes < 1 || row_lanes > 64 || (row_lanes & (row_lanes - 1))) return RWK_E_SIZE;
+    if (n * 64 >= (int64_t)0x7FFFFFFF * kBlock) return RWK_E_SIZE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int vec = (int)((d + 3) / 4);
+    if (vec == 1) return launch<1>(crow, col, val, n, d, x, y, accumulate, row_lanes, long_rows, n_long, long_threshold, stream);
+    if (vec == 2) return launch<2>(crow, col, val, n, d, x, y, accumulate, row_lanes, long_rows, n_long, long_threshold, stream);
+    if (vec <= 4) return launch<4>(crow, col, val, n, d, x, y, accumulate, row_lanes, long_rows, n_long, long_threshold, stream);
+    if (vec <= 8) return launch<8>(crow, col, val, n, d, x, y, accumulate, row_lanes, long_rows, n_long, long_threshold, stream);
+    return launch<16>(crow, col, val, n, d, x, y, accumulate, row_lanes, long_rows, n_long, long_threshold, stream);
+}

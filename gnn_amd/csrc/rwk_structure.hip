@@ -1,0 +1,168 @@
+// Graph-structure kernels: COO inspection, CSR construction, symmetry test, segment pointers.
+// Integer work only; every result is independent of thread scheduling (integer atomics are used
+// for counters and maxima only).
+#include "rwk_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__global__ void coo_inspect_kernel(const int64_t *__restrict__ rows, const int64_t *__restrict__ cols,
+                                   int64_t nnz, int64_t n, int32_t *flags) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    const int64_t r = rows[e], c = cols[e];
+    if (r < 0 || r >= n || c < 0 || c >= n) atomicAdd(&flags[1], 1);
+    if (e > 0) {
+        const int64_t pr = rows[e - 1], pc = cols[e - 1];
+        if (r < pr || (r == pr && c <= pc)) atomicAdd(&flags[0], 1);
+    }
+}
+
+// first index e in [0, nnz) with key[e] >= target
+__device__ inline int64_t lower_bound_i64(const int64_t *__restrict__ key, int64_t nnz, int64_t target) {
+    int64_t lo = 0, hi = nnz;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (key[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void csr_from_sorted_coo_kernel(const int64_t *__restrict__ rows, const int64_t *__restrict__ cols,
+                                           const float *__restrict__ vals, int64_t nnz, int64_t n,
+                                           int32_t *__restrict__ crow, int32_t *__restrict__ col,
+                                           float *__restrict__ val) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t <= n) crow[t] = (int32_t)lower_bound_i64(rows, nnz, t);
+    if (t < nnz) {
+        col[t] = (int32_t)cols[t];
+        val[t] = vals[t];
+    }
+}
+
+__global__ void csr_count_asymmetric_kernel(const int32_t *__restrict__ crow, const int32_t *__restrict__ col,
+                                            const float *__restrict__ val, int64_t n, int32_t *flag) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    int bad = 0;
+    for (int32_t j = crow[r]; j < crow[r + 1]; ++j) {
+        const int32_t c = col[j];
+        int32_t lo = crow[c], hi = crow[c + 1];
+        while (lo < hi) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (col[mid] < (int32_t)r) lo = mid + 1; else hi = mid;
+        }
+        const bool found = lo < crow[c + 1] && col[lo] == (int32_t)r &&
+                           __float_as_uint(val[lo]) == __float_as_uint(val[j]);
+        bad += found ? 0 : 1;
+    }
+    if (bad) atomicAdd(flag, bad);
+}
+
+__global__ void indicator_inspect_kernel(const int64_t *__restrict__ gi, int64_t n, int32_t *flags) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int64_t g = gi[p];
+    if (g < 0) {
+        atomicAdd(&flags[2], 1);
+    } else {
+        const int32_t g32 = g > 0x7FFFFFFF ? 0x7FFFFFFF : (int32_t)g;
+        atomicMax(&flags[1], g32);
+    }
+    if (p > 0 && g < gi[p - 1]) atomicAdd(&flags[0], 1);
+}
+
+__global__ void segments_build_kernel(const int64_t *__restrict__ ids, int64_t n, int64_t n_graphs,
+                                      int32_t *__restrict__ gid32, int32_t *__restrict__ seg_ptr,
+                                      int64_t *__restrict__ counts, float *__restrict__ counts_f32,
+                                      int32_t *empty) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) gid32[t] = (int32_t)ids[t];
+    if (t < n_graphs) {
+        const int64_t a = lower_bound_i64(ids, n, t);
+        const int64_t b = lower_bound_i64(ids, n, t + 1);
+        seg_ptr[t] = (int32_t)a;
+        counts[t] = b - a;
+        counts_f32[t] = (float)(b - a);
+        if (b == a) atomicAdd(empty, 1);
+        if (t == n_graphs - 1) seg_ptr[n_graphs] = (int32_t)b;
+    }
+}
+
+inline bool fits_i32(int64_t v) { return v >= 0 && v < 0x7FFFFFFFll; }
+
+}  // namespace
+
+extern "C" {
+
+int rwk_coo_inspect(const int64_t *rows, const int64_t *cols, int64_t nnz, int64_t n, int32_t *flags,
+                    rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(flags);
+    if (!fits_i32(nnz) || !fits_i32(n) || n == 0) return RWK_E_SIZE;
+    if (nnz == 0) return RWK_OK;
+    RWK_REQUIRE_PTR(rows);
+    RWK_REQUIRE_PTR(cols);
+    hipLaunchKernelGGL(coo_inspect_kernel, dim3((unsigned)rwk_ceil_div(nnz, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, rows, cols, nnz, n, flags);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
+int rwk_csr_from_sorted_coo(const int64_t *rows, const int64_t *cols, const float *vals, int64_t nnz,
+                            int64_t n, int32_t *crow, int32_t *col, float *val, rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(crow);
+    if (!fits_i32(nnz) || !fits_i32(n) || n == 0) return RWK_E_SIZE;
+    if (nnz > 0) {
+        RWK_REQUIRE_PTR(rows);
+        RWK_REQUIRE_PTR(cols);
+        RWK_REQUIRE_PTR(vals);
+        RWK_REQUIRE_PTR(col);
+        RWK_REQUIRE_PTR(val);
+    }
+    const int64_t work = (n + 1) > nnz ? (n + 1) : nnz;
+    hipLaunchKernelGGL(csr_from_sorted_coo_kernel, dim3((unsigned)rwk_ceil_div(work, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, rows, cols, vals, nnz, n, crow, col, val);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
+int rwk_csr_count_asymmetric(const int32_t *crow, const int32_t *col, const float *val, int64_t n,
+                             int32_t *flag, rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(crow);
+    RWK_REQUIRE_PTR(flag);
+    if (!fits_i32(n) || n == 0) return RWK_E_SIZE;
+    hipLaunchKernelGGL(csr_count_asymmetric_kernel, dim3((unsigned)rwk_ceil_div(n, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, crow, col, val, n, flag);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
+int rwk_indicator_inspect(const int64_t *gi, int64_t n, int32_t *flags, rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(gi);
+    RWK_REQUIRE_PTR(flags);
+    if (!fits_i32(n) || n == 0) return RWK_E_SIZE;
+    hipLaunchKernelGGL(indicator_inspect_kernel, dim3((unsigned)rwk_ceil_div(n, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, gi, n, flags);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
+int rwk_segments_build(const int64_t *ids_sorted, int64_t n, int64_t n_graphs, int32_t *gid32,
+                       int32_t *seg_ptr, int64_t *counts, float *counts_f32, int32_t *empty,
+                       rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(ids_sorted);
+    RWK_REQUIRE_PTR(gid32);
+    RWK_REQUIRE_PTR(seg_ptr);
+    RWK_REQUIRE_PTR(counts);
+    RWK_REQUIRE_PTR(counts_f32);
+    RWK_REQUIRE_PTR(empty);
+    if (!fits_i32(n) || n == 0 || n_graphs <= 0 || n_graphs > n) return RWK_E_SIZE;
+    const int64_t work = n > n_graphs ? n : n_graphs;
+    hipLaunchKernelGGL(segments_build_kernel, dim3((unsigned)rwk_ceil_div(work, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, ids_sorted, n, n_graphs, gid32, seg_ptr, counts, counts_f32, empty);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,126 @@
+"""``torch.autograd.Function`` around the HIP kernels of the random-walk-kernel layer.
+
+Replaces ``rwgnn2/model.py:43-67`` (sigmoid of the input projection, the ``max_step``-step
+propagation on the batch graph and on the hidden graphs, the (H*S) x N contraction, dropout,
+product, per-graph segment sum, normalisation and concatenation) and their autograd backward.
+
+Launch count per call: forward 3 + (L-1) kernels (+1 sigmoid), backward 2 + (L-1) (+ the sigmoid
+derivative).  All buffers are torch tensors; the library itself allocates nothing.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .structure import GraphStructure
+
+__all__ = ["rw_kernel_layer", "choose_stream_len"]
+
+# lanes we want in flight: 256 CUs x 4 SIMDs x 4 wavefronts x 64 lanes
+_TARGET_LANES = 256 * 4 * 4 * 64
+
+
+def _pow2_ceil(v: int) -> int:
+    p = 1
+    while p < v:
+        p *= 2
+    return p
+
+
+def choose_stream_len(n_nodes: int, n_hidden: int) -> int:
+    """Sorted positions walked sequentially by one lane group of the fused kernels."""
+    hp = _pow2_ceil(n_hidden)
+    want = -(-n_nodes * hp // _TARGET_LANES)
+    return max(16, min(512, want))
+
+
+class _RWKernelLayer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pre, adj_hidden, features_hidden, st: GraphStructure, max_step: int, normalize: bool,
+                drop_p: float, rng_state):
+        lib = _lib.load()
+        if not pre.is_cuda:
+            raise RuntimeError("gnn_amd runs on HIP devices only (no CPU fallback)")
+        dev = pre.device
+        n_hidden, s, d = features_hidden.shape
+        n, g, steps = st.n, st.n_graphs, int(max_step)
+        if pre.shape != (n, d):
+            raise ValueError(f"projected features have shape {tuple(pre.shape)}, expected {(n, d)}")
+        if n_hidden > 64 or d > 64 or steps > 4:
+            raise NotImplementedError(
+                "the HIP kernels cover hidden_graphs <= 64, hidden_dim <= 64, max_step <= 4 "
+                f"(got {n_hidden}, {d}, {steps})")
+        drop = float(drop_p) if (drop_p and rng_state is not None) else 0.0
+        with torch.cuda.device(dev):
+            stream = _lib.current_stream(dev)
+            adj_hidden_c = adj_hidden.detach().contiguous()
+            feat_c = features_hidden.detach().contiguous()
+            xs = torch.empty((steps, n, d), dtype=torch.float32, device=dev)
+            torch.sigmoid(pre.detach(), out=xs[0])                              # model.py:43
+            z = torch.empty((steps, n_hidden, s, d), dtype=torch.float32, device=dev)
+            ah = torch.empty((n_hidden, s, s), dtype=torch.float32, device=dev)
+            rng_used = torch.empty(2, dtype=torch.int64, device=dev) if drop else None
+            _lib.check(lib.rwk_hidden_forward(_lib.ptr(adj_hidden_c), feat_c.data_ptr(), n_hidden, s, d, steps,
+                                              ah.data_ptr(), z.data_ptr(),
+                                              _lib.ptr(rng_state) if drop else None, _lib.ptr(rng_used), stream),
+                       "rwk_hidden_forward")
+            for i in range(1, steps):
+                st.spmm(xs[i - 1], xs[i])                                        # model.py:55
+            stream_len = choose_stream_len(n, n_hidden)
+            slots = lib.rwk_fused_k_partials_size(n, stream_len, g, n_hidden, steps)
+            k_partials = torch.empty(slots, dtype=torch.float32, device=dev)
+            _lib.check(lib.rwk_fused_forward(xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm),
+                                             n, d, n_hidden, s, steps, stream_len, drop, _lib.ptr(rng_used),
+                                             k_partials.data_ptr(), stream), "rwk_fused_forward")
+            k = torch.empty((g, steps * n_hidden), dtype=torch.float32, device=dev)
+            _lib.check(lib.rwk_fused_reduce(k_partials.data_ptr(), st.seg_ptr.data_ptr(),
+                                            st.counts_f32.data_ptr(), g, n_hidden, steps, stream_len, drop,
+                                            int(bool(normalize)), k.data_ptr(), stream), "rwk_fused_reduce")
+        ctx.st = st
+        ctx.cfg = (steps, bool(normalize), drop, stream_len)
+        ctx.save_for_backward(xs, z, ah, adj_hidden_c, rng_used)
+        return k
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_k):
+        lib = _lib.load()
+        xs, z, ah, adj_hidden_c, rng_used = ctx.saved_tensors
+        st: GraphStructure = ctx.st
+        steps, normalize, drop, stream_len = ctx.cfg
+        _, n_hidden, s, d = z.shape
+        n = st.n
+        dev = xs.device
+        with torch.cuda.device(dev):
+            stream = _lib.current_stream(dev)
+            d_k = d_k.contiguous().float()
+            dx = torch.empty_like(xs)
+            n_part = lib.rwk_fused_dz_partials_count(n, stream_len, d, n_hidden, s, steps)
+            if n_part <= 0:
+                raise NotImplementedError("unsupported hyper-parameters for the fused backward kernel")
+            dz_partials = torch.empty((n_part, steps, n_hidden, s, d), dtype=torch.float32, device=dev)
+            _lib.check(lib.rwk_fused_backward(xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm),
+                                              d_k.data_ptr(), st.counts_f32.data_ptr(), n, d, n_hidden, s, steps,
+                                              stream_len, drop, int(normalize), _lib.ptr(rng_used),
+                                              dx.data_ptr(), dz_partials.data_ptr(), stream),
+                       "rwk_fused_backward")
+            for i in range(steps - 1, 0, -1):
+                st.spmm(dx[i], dx[i - 1], transpose=True, accumulate=True)      # dX[i-1] += A^T dX[i]
+            d_adj = torch.empty_like(adj_hidden_c)
+            d_feat = torch.empty((n_hidden, s, d), dtype=torch.float32, device=dev)
+            _lib.check(lib.rwk_hidden_backward(_lib.ptr(adj_hidden_c), ah.data_ptr(), z.data_ptr(),
+                                               dz_partials.data_ptr(), n_part, n_hidden, s, d, steps,
+                                               _lib.ptr(d_adj), d_feat.data_ptr(), stream),
+                       "rwk_hidden_backward")
+            x0 = xs[0]
+            d_pre = dx[0] * x0 * (1.0 - x0)                                      # sigmoid'
+        # with a single step adj_hidden never enters the forward pass: the reference leaves its
+        # .grad at None, and so do we
+        return d_pre, (d_adj if steps > 1 else None), d_feat, None, None, None, None, None
+
+
+def rw_kernel_layer(pre, adj_hidden, features_hidden, structure: GraphStructure, max_step: int,
+                    normalize: bool, drop_p: float = 0.0, rng_state=None):
+    """(G, max_step*H) random-walk-kernel features; ``pre`` is ``fc(features)`` BEFORE the sigmoid."""
+    return _RWKernelLayer.apply(pre, adj_hidden, features_hidden, structure, max_step, normalize, drop_p,
+                                rng_state)

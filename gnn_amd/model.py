@@ -1,0 +1,87 @@
+"""Drop-in ``RW_NN``: same constructor, ``forward(adj, features, graph_indicator)`` and
+``state_dict`` keys as ``rwgnn2/model.py:8-72`` (identical to ``rwgnn/model.py``), so that
+``from gnn_amd import RW_NN`` can replace ``from model import RW_NN`` in ``rwgnn2/main.py:12``.
+
+Lines :32-67 of the reference forward run in hand-written HIP kernels (``gnn_amd/csrc``);
+the input projection ``fc`` and the head (:68-72: batch-norm, two linears, log-softmax) stay
+ordinary torch modules.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.parameter import Parameter
+
+from .function import rw_kernel_layer
+from .structure import get_structure
+
+__all__ = ["RW_NN"]
+
+
+class RW_NN(nn.Module):
+    def __init__(self, input_dim, max_step, hidden_graphs, size_hidden_graphs, hidden_dim, penultimate_dim,
+                 normalize, n_classes, dropout, device):
+        super().__init__()
+        self.max_step = max_step
+        self.hidden_graphs = hidden_graphs
+        self.size_hidden_graphs = size_hidden_graphs
+        self.normalize = normalize
+        self.device = device
+        n_pairs = (size_hidden_graphs * (size_hidden_graphs - 1)) // 2
+        # parameter names, shapes and creation order follow model.py:16-21 (same state_dict, same
+        # consumption of the global RNG at construction)
+        self.adj_hidden = Parameter(torch.empty(hidden_graphs, n_pairs))
+        self.features_hidden = Parameter(torch.empty(hidden_graphs, size_hidden_graphs, hidden_dim))
+        self.fc = nn.Linear(input_dim, hidden_dim)
+        self.bn = nn.BatchNorm1d(hidden_graphs * max_step)
+        self.fc1 = nn.Linear(hidden_graphs * max_step, penultimate_dim)
+        self.fc2 = nn.Linear(penultimate_dim, n_classes)
+        self.dropout = nn.Dropout(p=dropout)
+        self.relu = nn.ReLU()
+        self.sigmoid = nn.Sigmoid()
+        # {seed, offset} of the counter-based dropout mask; lives on the device so that a captured
+        # HIP graph advances it on replay.  Not part of the state_dict (the reference has no such key).
+        self.register_buffer("_rng_state", torch.zeros(2, dtype=torch.int64), persistent=False)
+        self._rng_seeded = False
+        self.init_weights()
+
+    def init_weights(self):
+        """model.py:27-29."""
+        self.adj_hidden.data.uniform_(-1, 1)
+        self.features_hidden.data.uniform_(0, 1)
+
+    def seed_dropout(self, seed: int, offset: int = 0):
+        """Fix the dropout stream (otherwise seeded from torch's global CPU generator on first use)."""
+        self._rng_state.copy_(torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, offset], dtype=torch.int64))
+        self._rng_seeded = True
+
+    def forward(self, adj, features, graph_indicator):
+        structure = get_structure(adj, graph_indicator)
+        p = float(self.dropout.p)
+        drop = p if self.training else 0.0
+        pre = self.fc(features)
+        if drop >= 1.0:
+            # every product is dropped (model.py:58 with p = 1): K is exactly zero
+            k = pre.new_zeros(structure.n_graphs, self.hidden_graphs * self.max_step)
+            k = k + 0.0 * (pre.sum() + self.features_hidden.sum() + self.adj_hidden.sum())
+        else:
+            if drop > 0.0 and not self._rng_seeded:
+                self.seed_dropout(int(torch.randint(0, 2 ** 62, (1,)).item()))
+            k = rw_kernel_layer(pre, self.adj_hidden, self.features_hidden, structure, self.max_step,
+                                bool(self.normalize), drop, self._rng_state if drop > 0.0 else None)
+        out = self.bn(k)
+        out = self.relu(self.fc1(out))
+        out = self.dropout(out)
+        out = self.fc2(out)
+        return F.log_softmax(out, dim=1)
+
+    def rw_features(self, adj, features, graph_indicator):
+        """The (G, max_step*H) input of ``bn`` (model.py:67), for tests and benchmarks."""
+        structure = get_structure(adj, graph_indicator)
+        drop = float(self.dropout.p) if self.training else 0.0
+        if drop > 0.0 and not self._rng_seeded:
+            self.seed_dropout(int(torch.randint(0, 2 ** 62, (1,)).item()))
+        return rw_kernel_layer(self.fc(features), self.adj_hidden, self.features_hidden, structure,
+                               self.max_step, bool(self.normalize), drop,
+                               self._rng_state if drop > 0.0 else None)

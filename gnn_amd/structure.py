@@ -1,0 +1,233 @@
+"""Per-batch graph structure on the device: CSR of A and of A^T, sorted-segment metadata, SpMM schedule.
+
+The reference re-derives all of this inside ``torch.spmm`` (COO -> CSR) and ``torch.unique``
+(a full sort) on every forward call (``rwgnn2/model.py:32,55``).  Batches are built once per
+fold and reused every epoch (``rwgnn2/main.py:70-72``), so here it is computed once per
+``(adj, graph_indicator)`` pair and cached by tensor identity.
+
+Integer results (CSR arrays, per-graph node counts, graph ids) are bit-exact with
+``adj.coalesce().to_sparse_csr()`` and ``torch.unique(graph_indicator, return_counts=True)``.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+__all__ = ["GraphStructure", "get_structure", "clear_structure_cache"]
+
+
+class _Csr:
+    __slots__ = ("crow", "col", "val", "row_lanes", "long_rows", "long_threshold", "max_degree")
+
+    def __init__(self, crow, col, val):
+        self.crow, self.col, self.val = crow, col, val
+        self.row_lanes = 1
+        self.long_rows = None
+        self.long_threshold = 0
+        self.max_degree = 0
+
+
+def _pow2_floor(v: int) -> int:
+    p = 1
+    while p * 2 <= v:
+        p *= 2
+    return p
+
+
+def spmm_schedule(n: int, nnz: int, max_degree: int):
+    """Degree-histogram rule for the SpMM launch shape: lanes per row and the long-row cut.
+
+    Mean degree below 8 (molecules, proteins): one lane group per row.  Denser rows share their
+    entries over up to 16 lanes.  Rows above ``128 * row_lanes`` entries (power-law hubs) leave
+    the packed pass and get a wavefront each.
+    """
+    mean = nnz / max(n, 1)
+    row_lanes = 1 if mean < 8 else min(16, _pow2_floor(int(mean // 4)))
+    long_threshold = 128 * row_lanes
+    return row_lanes, (long_threshold if max_degree > long_threshold else 0)
+
+
+class GraphStructure:
+    """Device-resident structure of one batch.  Build with :meth:`build` (or :func:`get_structure`)."""
+
+    def __init__(self):
+        self.device = None
+        self.n = 0
+        self.nnz = 0
+        self.n_graphs = 0
+        self.csr: Optional[_Csr] = None
+        self.csr_t: Optional[_Csr] = None      # the same object as ``csr`` when A == A^T
+        self.symmetric = False
+        self.gid = None          # int32 (N): graph id at each sorted position
+        self.perm = None         # int32 (N) node index at each sorted position, or None if already sorted
+        self.seg_ptr = None      # int32 (G+1)
+        self.counts = None       # int64 (G)  == torch.unique(..., return_counts=True)[1]
+        self.counts_f32 = None   # float32 (G)
+        self._keepalive = ()
+
+    # ------------------------------------------------------------------------------------
+    @staticmethod
+    def build(adj: torch.Tensor, graph_indicator: torch.Tensor) -> "GraphStructure":
+        lib = _lib.load()
+        if adj.layout != torch.sparse_coo:
+            raise TypeError("adj must be a torch sparse COO tensor (as built by generate_batches)")
+        if adj.dim() != 2 or adj.shape[0] != adj.shape[1]:
+            raise ValueError("adj must be square (N x N)")
+        if not adj.is_cuda:
+            raise RuntimeError("gnn_amd runs on HIP devices only: adj is on %s (no CPU fallback)" % adj.device)
+        if adj.dtype != torch.float32:
+            raise TypeError("adj values must be float32")
+        n = adj.shape[0]
+        if graph_indicator.dim() != 1 or graph_indicator.shape[0] != n:
+            raise ValueError("graph_indicator must have one entry per node")
+        if graph_indicator.dtype != torch.int64:
+            raise TypeError("graph_indicator must be int64 (torch.LongTensor)")
+        if graph_indicator.device != adj.device:
+            raise RuntimeError("adj and graph_indicator must be on the same device")
+        if n == 0:
+            raise ValueError("empty batch")
+        dev = adj.device
+        st = GraphStructure()
+        st.device = dev
+        st.n = n
+        with torch.cuda.device(dev):
+            stream = _lib.current_stream(dev)
+            idx = adj._indices()
+            vals = adj._values().contiguous()
+            rows = idx[0].contiguous()
+            cols = idx[1].contiguous()
+            gi = graph_indicator.contiguous()
+            nnz_in = rows.numel()
+            flags = torch.zeros(8, dtype=torch.int32, device=dev)
+            _lib.check(lib.rwk_coo_inspect(_lib.ptr(rows), _lib.ptr(cols), nnz_in, n, flags.data_ptr(), stream),
+                       "rwk_coo_inspect")
+            _lib.check(lib.rwk_indicator_inspect(gi.data_ptr(), n, flags[4:].data_ptr(), stream),
+                       "rwk_indicator_inspect")
+            f = flags.cpu().tolist()                      # host sync #1 (once per batch)
+            unsorted_coo, out_of_range = f[0], f[1]
+            gi_unsorted, gi_max, gi_negative = f[4], f[5], f[6]
+            if out_of_range:
+                raise IndexError("adj has indices outside [0, N)")
+            if gi_negative:
+                raise IndexError("graph_indicator has negative ids")
+            n_graphs = gi_max + 1
+            if n_graphs > n:
+                raise IndexError("graph_indicator ids must cover 0..G-1 without gaps")
+            if unsorted_coo:
+                # rare path (hand-built inputs): let torch sort and sum duplicates exactly as
+                # torch.spmm's own coalesce would
+                co = adj.coalesce()
+                idx = co.indices()
+                rows, cols, vals = idx[0].contiguous(), idx[1].contiguous(), co.values().contiguous()
+            st.csr = st._csr_from_sorted(lib, rows, cols, vals, n, stream)
+            st.nnz = int(rows.numel())
+
+            if gi_unsorted:
+                ids_sorted, order = torch.sort(gi, stable=True)
+                st.perm = order.to(torch.int32)
+            else:
+                ids_sorted = gi
+            st.n_graphs = n_graphs
+            st.gid = torch.empty(n, dtype=torch.int32, device=dev)
+            st.seg_ptr = torch.empty(n_graphs + 1, dtype=torch.int32, device=dev)
+            st.counts = torch.empty(n_graphs, dtype=torch.int64, device=dev)
+            st.counts_f32 = torch.empty(n_graphs, dtype=torch.float32, device=dev)
+            flags2 = torch.zeros(4, dtype=torch.int32, device=dev)
+            _lib.check(lib.rwk_segments_build(ids_sorted.data_ptr(), n, n_graphs, st.gid.data_ptr(),
+                                              st.seg_ptr.data_ptr(), st.counts.data_ptr(),
+                                              st.counts_f32.data_ptr(), flags2[1:].data_ptr(), stream),
+                       "rwk_segments_build")
+            if st.nnz:
+                _lib.check(lib.rwk_csr_count_asymmetric(st.csr.crow.data_ptr(), st.csr.col.data_ptr(),
+                                                        st.csr.val.data_ptr(), n, flags2.data_ptr(), stream),
+                           "rwk_csr_count_asymmetric")
+                deg = st.csr.crow[1:] - st.csr.crow[:-1]
+                flags2[2] = deg.max()
+            f2 = flags2.cpu().tolist()                    # host sync #2
+            if f2[1]:
+                raise IndexError("graph_indicator ids must cover 0..G-1 without gaps")
+            st.symmetric = f2[0] == 0
+            st._schedule(st.csr, f2[2])
+            if st.symmetric:
+                st.csr_t = st.csr
+            else:
+                t = torch.sparse_coo_tensor(torch.stack([cols, rows]), vals, (n, n)).coalesce()
+                ti = t.indices()
+                st.csr_t = st._csr_from_sorted(lib, ti[0].contiguous(), ti[1].contiguous(),
+                                               t.values().contiguous(), n, stream)
+                tdeg = st.csr_t.crow[1:] - st.csr_t.crow[:-1]
+                st._schedule(st.csr_t, int(tdeg.max().item()))
+        return st
+
+    @staticmethod
+    def _csr_from_sorted(lib, rows, cols, vals, n, stream) -> _Csr:
+        dev = rows.device
+        nnz = rows.numel()
+        crow = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)[:nnz]
+        val = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev)[:nnz]
+        _lib.check(lib.rwk_csr_from_sorted_coo(_lib.ptr(rows), _lib.ptr(cols), _lib.ptr(vals), nnz, n,
+                                               crow.data_ptr(), col.data_ptr(), val.data_ptr(), stream),
+                   "rwk_csr_from_sorted_coo")
+        return _Csr(crow, col, val)
+
+    def _schedule(self, csr: _Csr, max_degree: int):
+        csr.max_degree = int(max_degree)
+        csr.row_lanes, csr.long_threshold = spmm_schedule(self.n, self.nnz, csr.max_degree)
+        if csr.long_threshold:
+            deg = csr.crow[1:] - csr.crow[:-1]
+            csr.long_rows = torch.nonzero(deg > csr.long_threshold).flatten().to(torch.int32)
+
+    # ------------------------------------------------------------------------------------
+    def spmm(self, x: torch.Tensor, y: torch.Tensor, transpose: bool = False, accumulate: bool = False):
+        """y = A x (or A^T x), optionally accumulated into y.  x, y: contiguous (N, D) float32."""
+        lib = _lib.load()
+        csr = self.csr_t if transpose else self.csr
+        n_long = 0 if csr.long_rows is None else csr.long_rows.numel()
+        _lib.check(lib.rwk_spmm_csr(csr.crow.data_ptr(), _lib.ptr(csr.col), _lib.ptr(csr.val), self.n,
+                                    x.shape[1], x.data_ptr(), y.data_ptr(), int(accumulate), csr.row_lanes,
+                                    _lib.ptr(csr.long_rows), n_long, csr.long_threshold,
+                                    _lib.current_stream(self.device)), "rwk_spmm_csr")
+
+    def spmm_bytes(self, d: int) -> int:
+        """Algorithmic HBM bytes of one SpMM launch: values + columns + row pointers + x + y."""
+        return self.nnz * 8 + (self.n + 1) * 4 + 2 * self.n * d * 4
+
+
+# ----------------------------------------------------------------------------------------
+# cache keyed by tensor identity
+# ----------------------------------------------------------------------------------------
+_CACHE: "OrderedDict[tuple, GraphStructure]" = OrderedDict()
+_CACHE_CAPACITY = 512
+
+
+def _key(adj, graph_indicator):
+    idx, val = adj._indices(), adj._values()
+    return (idx.data_ptr(), val.data_ptr(), graph_indicator.data_ptr(), idx.shape[1], adj.shape[0],
+            idx._version, val._version, graph_indicator._version, str(adj.device))
+
+
+def get_structure(adj, graph_indicator) -> GraphStructure:
+    """Cached :meth:`GraphStructure.build`.  The cache entry keeps the key tensors alive, so a
+    data pointer cannot be reused by another batch while its entry exists."""
+    if isinstance(adj, GraphStructure):
+        return adj
+    key = _key(adj, graph_indicator)
+    st = _CACHE.get(key)
+    if st is not None:
+        _CACHE.move_to_end(key)
+        return st
+    st = GraphStructure.build(adj, graph_indicator)
+    st._keepalive = (adj, graph_indicator)
+    _CACHE[key] = st
+    while len(_CACHE) > _CACHE_CAPACITY:
+        _CACHE.popitem(last=False)
+    return st
+
+
+def clear_structure_cache():
+    _CACHE.clear()

@@ -1,0 +1,170 @@
+/*
+ * librwk -- MI355X (gfx950) kernels for the random-walk-kernel layer of RW_NN.
+ *
+ * C ABI only: plain pointers and sizes, no torch types.  Every pointer argument is a DEVICE
+ * pointer unless its comment says "host".  Every function enqueues work on `stream`
+ * (a hipStream_t passed as void*; never the null stream implicitly) and returns immediately;
+ * the return value is RWK_OK or a negative RWK_E_* code (bad arguments are rejected on the
+ * host before anything is launched) or a positive hipError_t from the launch.
+ * The library never allocates or frees device memory and keeps no mutable global state:
+ * the caller owns inputs, outputs and workspaces.
+ *
+ * The reference (Xiang227/GNN) has no native interface; each entry point below replaces the
+ * PyTorch operators of the cited lines of rwgnn2/model.py (identical to rwgnn/model.py).
+ *
+ * Index types inside the kernels are int32: N, nnz, G must be < 2^31.
+ * Layouts (all row-major, float32 unless noted):
+ *   X      (L, N, D)   X[0] = sigmoid(fc(features)), X[i] = A X[i-1]
+ *   Z      (L, H, S, D) Z[0] = features_hidden,      Z[i] = Ah Z[i-1]
+ *   Ah     (H, S, S)   symmetric hidden adjacency
+ *   K      (G, L*H)    column i*H + h                               (model.py:67)
+ *   CSR    crow int32 (N+1), col int32 (nnz), val float32 (nnz)
+ *   nodes are visited in "sorted position" order p = 0..N-1: node(p) = perm ? perm[p] : p,
+ *   gid[p] = graph id of node(p), non-decreasing in p; seg_ptr[g] = first p of graph g.
+ */
+#ifndef RWK_H_
+#define RWK_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RWK_VERSION 100
+
+#define RWK_OK 0
+#define RWK_E_NULL (-1)        /* a required pointer is null */
+#define RWK_E_SIZE (-2)        /* a size is negative, zero where it must not be, or too large */
+#define RWK_E_UNSUPPORTED (-3) /* hyper-parameters outside what the kernels are built for */
+#define RWK_E_ALIGN (-4)       /* a pointer is not aligned as documented */
+
+typedef void *rwk_stream_t;
+
+int rwk_version(void);
+const char *rwk_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------
+ * Graph structure (integer work; results must be bit-exact).
+ * ------------------------------------------------------------------------------------- */
+
+/* Inspect a COO edge list (what utils.py:38-44 hands to the model as `adj`).
+ * flags (int32[4], device) receives:
+ *   [0] = number of positions e>0 where (row,col)[e] <= (row,col)[e-1]  (0 <=> strictly
+ *         row-major sorted, hence duplicate-free: the layout generate_batches produces)
+ *   [1] = number of entries with row or col outside [0, n)
+ * flags must be zeroed by the caller. */
+int rwk_coo_inspect(const int64_t *rows, const int64_t *cols, int64_t nnz, int64_t n,
+                    int32_t *flags, rwk_stream_t stream);
+
+/* CSR of a strictly row-major sorted COO list; replaces the COO->CSR conversion inside
+ * torch.spmm (model.py:55).  crow has n+1 entries. */
+int rwk_csr_from_sorted_coo(const int64_t *rows, const int64_t *cols, const float *vals,
+                            int64_t nnz, int64_t n, int32_t *crow, int32_t *col, float *val,
+                            rwk_stream_t stream);
+
+/* flag (int32[1], zeroed by caller) += number of stored entries (r,c,v) for which (c,r) is
+ * missing or holds a different value: 0 <=> A == A^T bit for bit, so A^T x may reuse A's CSR. */
+int rwk_csr_count_asymmetric(const int32_t *crow, const int32_t *col, const float *val,
+                             int64_t n, int32_t *flag, rwk_stream_t stream);
+
+/* Inspect graph_indicator (model.py:32).  flags (int32[4], zeroed by caller):
+ *   [0] = number of positions p>0 with gi[p] < gi[p-1]  (0 <=> already sorted)
+ *   [1] = max id, [2] = number of negative ids. */
+int rwk_indicator_inspect(const int64_t *gi, int64_t n, int32_t *flags, rwk_stream_t stream);
+
+/* From graph ids in sorted-position order (int64, non-decreasing, values in [0,G)):
+ * gid32[p] = (int32) ids[p]; seg_ptr[g] = first p with ids[p] >= g (g = 0..G);
+ * counts[g] = seg_ptr[g+1]-seg_ptr[g] as int64 (the `counts` of torch.unique, model.py:32);
+ * counts_f32[g] = (float)counts[g], the divisor of model.py:63-64.  empty (int32[1], zeroed) += number of
+ * graphs with no node (the reference would raise on such input). */
+int rwk_segments_build(const int64_t *ids_sorted, int64_t n, int64_t n_graphs, int32_t *gid32,
+                       int32_t *seg_ptr, int64_t *counts, float *counts_f32, int32_t *empty,
+                       rwk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * (1) CSR SpMM   y = A x (+ y)          replaces torch.spmm, model.py:55, and its backward
+ * ------------------------------------------------------------------------------------- */
+
+/* x, y: (n, d) row-major, d <= 64.  accumulate != 0: y += A x.
+ * row_lanes (power of two, 1..64): lanes that share the stored entries of one row in the
+ * packed pass; the caller picks it from the degree histogram (1 for degree <= ~8).
+ * When long_rows != NULL and n_long > 0, rows with more than `long_threshold` entries are
+ * skipped by the packed pass and must be listed in long_rows (n_long of them, ascending):
+ * each is then summed by a whole wavefront.  Summation order is fixed in both passes. */
+int rwk_spmm_csr(const int32_t *crow, const int32_t *col, const float *val, int64_t n, int64_t d,
+                 const float *x, float *y, int accumulate, int32_t row_lanes,
+                 const int32_t *long_rows, int64_t n_long, int32_t long_threshold,
+                 rwk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * (2) hidden graphs   Ah = sym(triu(relu(adj_hidden))),  Z[i] = Ah Z[i-1]
+ *     replaces model.py:39-42 and :56 for all steps in one launch.
+ * ------------------------------------------------------------------------------------- */
+
+/* adj_hidden (H, S(S-1)/2), features_hidden (H,S,D) -> ah (H,S,S), z (L,H,S,D).
+ * rng_state / rng_used: optional uint64[2] {seed, offset}.  When both are non-null the
+ * launch copies *rng_state to *rng_used and then increments rng_state[1], entirely on the
+ * device, so that a captured graph draws a fresh dropout mask on every replay. */
+int rwk_hidden_forward(const float *adj_hidden, const float *features_hidden, int64_t h, int64_t s,
+                       int64_t d, int64_t max_step, float *ah, float *z, uint64_t *rng_state,
+                       uint64_t *rng_used, rwk_stream_t stream);
+
+/* Backward of the chain.  dz_partials (n_partials, L, H, S, D): per-workgroup partial sums of
+ * the direct gradient of each Z[i] written by rwk_fused_backward; they are added in index
+ * order (deterministic).  Outputs d_adj_hidden (H, S(S-1)/2), d_features_hidden (H,S,D). */
+int rwk_hidden_backward(const float *adj_hidden, const float *ah, const float *z,
+                        const float *dz_partials, int64_t n_partials, int64_t h, int64_t s,
+                        int64_t d, int64_t max_step, float *d_adj_hidden,
+                        float *d_features_hidden, rwk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * (3)+(4) fused random-walk kernel   replaces model.py:45, :53, :57-64, :67 and backward
+ *
+ *   K[g, i*H+h] = c_g * sum_{p in g} sum_s m[i,h,s,n] * (Z0[h,s].X0[n]) * (Zi[h,s].Xi[n])
+ *
+ * The (H*S) x N products never leave registers.  Dropout (model.py:58) is a counter-based
+ * Philox4x32-10 mask regenerated identically in backward from rng (uint64[2] {seed,offset},
+ * device memory; NULL or drop_p == 0 means no dropout).
+ *
+ * Work split: "streams" of `stream_len` consecutive sorted positions; stream c covers
+ * p in [c*stream_len, (c+1)*stream_len).  Partial sums of stream c for graph g go to slot
+ * c + g of `k_partials` ((n_streams + G) x L*H floats); rwk_fused_reduce adds the slots of
+ * each graph in increasing c and applies c_g (1/(1-p), and 1/|g| when normalize).
+ * ------------------------------------------------------------------------------------- */
+
+/* Workspace sizes in floats (pure functions, host side). */
+int64_t rwk_fused_n_streams(int64_t n, int64_t stream_len);
+int64_t rwk_fused_k_partials_size(int64_t n, int64_t stream_len, int64_t n_graphs, int64_t h,
+                                  int64_t max_step);
+/* Number of (L,H,S,D) partial slabs rwk_fused_backward writes (= its workgroup count);
+ * 0 when the hyper-parameters are unsupported. */
+int64_t rwk_fused_dz_partials_count(int64_t n, int64_t stream_len, int64_t d, int64_t h, int64_t s,
+                                    int64_t max_step);
+
+int rwk_fused_forward(const float *x, const float *z, const int32_t *gid, const int32_t *perm,
+                      int64_t n, int64_t d, int64_t h, int64_t s, int64_t max_step,
+                      int64_t stream_len, float drop_p, const uint64_t *rng, float *k_partials,
+                      rwk_stream_t stream);
+
+int rwk_fused_reduce(const float *k_partials, const int32_t *seg_ptr, const float *counts_f32,
+                     int64_t n_graphs, int64_t h, int64_t max_step, int64_t stream_len,
+                     float drop_p, int normalize, float *k, rwk_stream_t stream);
+
+/* d_k (G, L*H) -> dx (L, N, D): the DIRECT gradient of each X[i] (the caller then chains
+ * dx[i-1] += A^T dx[i] with rwk_spmm_csr), and dz_partials (see rwk_hidden_backward). */
+int rwk_fused_backward(const float *x, const float *z, const int32_t *gid, const int32_t *perm,
+                       const float *d_k, const float *counts_f32, int64_t n, int64_t d, int64_t h,
+                       int64_t s, int64_t max_step, int64_t stream_len, float drop_p,
+                       int normalize, const uint64_t *rng, float *dx, float *dz_partials,
+                       rwk_stream_t stream);
+
+/* Test hook: writes the keep-mask exactly as the fused kernels draw it, one byte per element,
+ * shape (L, H, S, N), for the {seed, offset} in rng. */
+int rwk_dropout_mask(const uint64_t *rng, int64_t n, int64_t h, int64_t s, int64_t max_step,
+                     float drop_p, uint8_t *keep, rwk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RWK_H_ */

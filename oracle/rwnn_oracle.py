@@ -267,34 +267,40 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return c0, c1, c2, c3
 
 
-def dropout_threshold(drop_p: float) -> int:
-    """Keep iff a 16-bit uniform is < this.  round((1-p) * 65536), clamped to [0, 65536]."""
-    t = int(np.floor((1.0 - float(drop_p)) * 65536.0 + 0.5))
-    return max(0, min(65536, t))
+def dropout_thresholds(drop_p: float):
+    """(T0, T1): keep iff byte < T0, or byte == T0 and the call's tie byte < T1."""
+    q = min(1.0, max(0.0, 1.0 - float(drop_p)))
+    a = q * 256.0
+    t0 = min(256, int(a))
+    t1 = min(255, int((a - t0) * 256.0))
+    return t0, t1
 
 
 def dropout_keep(seed: int, offset: int, n_nodes: int, h: int, s: int, max_step: int, drop_p: float):
-    """Boolean keep-mask (max_step, H, S, N) exactly as the HIP kernels draw it.
+    """Boolean keep-mask (max_step, H, S, N) exactly as the HIP kernels draw it
+    (specification in gnn_amd/csrc/rwk_common.h).
 
-    One Philox stream per (node n, hidden graph h): counter = (n, h, call, offset_lo ^ (offset_hi<<?))
-    -- see the body; sample e = s*L + i of the stream is 16-bit field (e % 8) of call (e // 8):
-    word (e%8)//2, low half for even fields, high half for odd ones.
+    One Philox4x32-10 stream per (node n, hidden graph h): call c has counter
+    (n, h, c, offset_lo) and key (seed_lo, seed_hi ^ offset_hi).  Element (step i, hidden node s)
+    is sample e = s*L + i: byte (e % 15) of call (e // 15), byte j being bits [8(j&3), 8(j&3)+8) of
+    output word j>>2.  Byte 15 of each call breaks ties.
     """
-    thr = dropout_threshold(drop_p)
+    t0, t1 = dropout_thresholds(drop_p)
     n_samples = s * max_step
-    n_calls = (n_samples + 7) // 8
+    n_calls = (n_samples + 14) // 15
     nn = np.arange(n_nodes, dtype=np.uint32)[None, :, None]
     hh = np.arange(h, dtype=np.uint32)[:, None, None]
     cc = np.arange(n_calls, dtype=np.uint32)[None, None, :]
+    zero = np.uint32(0) * (nn + hh + cc)
     off_lo = np.uint32(offset & 0xFFFFFFFF)
     off_hi = np.uint32((offset >> 32) & 0xFFFFFFFF)
     k0 = np.uint32(seed & 0xFFFFFFFF)
-    k1 = np.uint32((seed >> 32) & 0xFFFFFFFF)
-    w = philox4x32_10(nn, hh, cc + np.uint32(0) * nn, off_lo + np.uint32(0) * nn, k0, k1 ^ off_hi)
-    words = np.stack(w, axis=-1)                      # (H, N, calls, 4)
-    lo = (words & np.uint32(0xFFFF)).astype(np.uint32)
-    hi = (words >> np.uint32(16)).astype(np.uint32)
-    fields = np.stack([lo, hi], axis=-1).reshape(h, n_nodes, n_calls * 8)   # field = 2*word + half
-    fields = fields[:, :, :n_samples].reshape(h, n_nodes, s, max_step)
-    keep = fields < np.uint32(thr)
-    return np.ascontiguousarray(keep.transpose(3, 0, 2, 1))   # (L, H, S, N)
+    k1 = np.uint32((seed >> 32) & 0xFFFFFFFF) ^ off_hi
+    w = philox4x32_10(nn + zero, hh + zero, cc + zero, off_lo + zero, k0, k1)
+    words = np.stack(w, axis=-1)                                   # (H, N, calls, 4)
+    shifts = np.array([0, 8, 16, 24], dtype=np.uint32)
+    by = ((words[..., :, None] >> shifts) & np.uint32(0xFF)).reshape(h, n_nodes, n_calls, 16)
+    tie = by[..., 15:16] < t1
+    keep = (by[..., :15] < t0) | ((by[..., :15] == t0) & tie)       # (H, N, calls, 15)
+    keep = keep.reshape(h, n_nodes, n_calls * 15)[:, :, :n_samples].reshape(h, n_nodes, s, max_step)
+    return np.ascontiguousarray(keep.transpose(3, 0, 2, 1))         # (L, H, S, N)

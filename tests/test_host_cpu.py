@@ -1,0 +1,106 @@
+"""CPU-side checks: the C-ABI library loads and exports what include/rwk.h declares, the module mirrors the
+reference's interface, and the product path refuses to run without a HIP device (no CPU fallback)."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "rwk.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(rwk_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    from gnn_amd import _lib
+    lib = _lib.load()
+    declared = _declared_functions()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(_lib.SIGNATURES) == declared
+    assert lib.rwk_version() == 100
+    assert lib.rwk_error_string(-3).decode().startswith("hyper-parameters")
+
+
+def test_header_argument_counts_match_binding():
+    from gnn_amd import _lib
+    text = open(os.path.join(ROOT, "include", "rwk.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for name, (_, argtypes) in _lib.SIGNATURES.items():
+        m = re.search(r"\b%s\s*\(([^)]*)\)" % name, text)
+        assert m, name
+        args = m.group(1).strip()
+        n_args = 0 if args in ("", "void") else len(args.split(","))
+        assert n_args == len(argtypes), name
+
+
+def test_workspace_size_functions_are_pure_host_code():
+    from gnn_amd import _lib
+    lib = _lib.load()
+    assert lib.rwk_fused_n_streams(1000, 16) == 63
+    assert lib.rwk_fused_k_partials_size(1000, 16, 10, 16, 2) == (63 + 10) * 32
+    # 16 hidden graphs -> 16 lanes per stream, 256-thread workgroups -> 16 streams per workgroup
+    assert lib.rwk_fused_dz_partials_count(1000, 16, 4, 16, 5, 2) == 4
+    assert lib.rwk_fused_dz_partials_count(1000, 16, 4, 65, 5, 2) == 0     # unsupported: H > 64
+
+
+def test_module_mirrors_reference_interface():
+    from gnn_amd import RW_NN
+    torch.manual_seed(0)
+    m = RW_NN(1, 2, 16, 5, 4, 32, False, 2, 0.2, "cpu")
+    keys = list(m.state_dict().keys())
+    assert keys == ["adj_hidden", "features_hidden", "fc.weight", "fc.bias", "bn.weight", "bn.bias",
+                    "bn.running_mean", "bn.running_var", "bn.num_batches_tracked", "fc1.weight", "fc1.bias",
+                    "fc2.weight", "fc2.bias"]
+    assert m.adj_hidden.shape == (16, 10) and m.features_hidden.shape == (16, 5, 4)
+    assert float(m.adj_hidden.min()) >= -1 and float(m.adj_hidden.max()) <= 1
+    assert float(m.features_hidden.min()) >= 0 and float(m.features_hidden.max()) <= 1
+    assert m.max_step == 2 and m.hidden_graphs == 16 and m.size_hidden_graphs == 5 and m.normalize is False
+
+
+def test_same_initial_weights_as_reference_rule():
+    """Construction consumes the global RNG in the reference's order (model.py:16-29): parameters are
+    created uninitialised, the Linear/BatchNorm modules draw theirs, then adj_hidden and features_hidden."""
+    from gnn_amd import RW_NN
+    torch.manual_seed(3)
+    m = RW_NN(3, 2, 4, 3, 5, 6, True, 2, 0.0, "cpu")
+    torch.manual_seed(3)
+    fc = torch.nn.Linear(3, 5)
+    torch.nn.BatchNorm1d(8)
+    fc1 = torch.nn.Linear(8, 6)
+    fc2 = torch.nn.Linear(6, 2)
+    adj_hidden = torch.empty(4, 3).uniform_(-1, 1)
+    feat_hidden = torch.empty(4, 3, 5).uniform_(0, 1)
+    assert torch.equal(m.fc.weight, fc.weight) and torch.equal(m.fc1.weight, fc1.weight)
+    assert torch.equal(m.fc2.bias, fc2.bias)
+    assert torch.equal(m.adj_hidden, adj_hidden) and torch.equal(m.features_hidden, feat_hidden)
+
+
+def test_no_cpu_fallback():
+    from gnn_amd import RW_NN
+    m = RW_NN(1, 2, 4, 3, 4, 8, False, 2, 0.0, "cpu")
+    idx = torch.tensor([[0, 1], [1, 0]])
+    adj = torch.sparse_coo_tensor(idx, torch.ones(2), (3, 3))
+    with pytest.raises(RuntimeError, match="HIP devices only"):
+        m(adj, torch.ones(3, 1), torch.tensor([0, 0, 1]))
+
+
+def test_spmm_schedule_rule():
+    from gnn_amd.structure import spmm_schedule
+    assert spmm_schedule(1168, 2590, 4) == (1, 0)
+    assert spmm_schedule(3000, 7000, 900) == (1, 128)
+    lanes, thr = spmm_schedule(1000, 64000, 80)
+    assert lanes == 16 and thr == 0
+
+
+def test_stream_length_rule():
+    from gnn_amd.function import choose_stream_len
+    assert choose_stream_len(1168, 16) == 16
+    assert choose_stream_len(307000, 16) == 19
+    assert choose_stream_len(50_000_000, 16) == 512
