@@ -1,0 +1,312 @@
+#!/usr/bin/env python3
+"""Benchmark of the RW_NN training step on MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step is the reference's ``train()`` (rwgnn2/main.py:82-88) on one resident batch: zero the gradients,
+``model(adj, features, graph_indicator)``, cross-entropy, backward, (gradient all-reduce over the ranks),
+Adam update.  The workload is BASELINE.json configs[1]: 1024 PROTEINS/D&D-scale graphs (100..500 nodes, mean
+degree 3.7) per GPU, main.py's default hyper-parameters (16 hidden graphs x 5 nodes, hidden_dim 4, max_step 2,
+dropout 0.2).  Each rank holds its own batch (weak scaling); value = graphs of all ranks / slowest rank's time.
+
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  "roofline":     the dominant hand-written kernel: algorithmic HBM bytes per launch / its launch duration
+                  (HIP events on the launch stream, inside this process), against the 8 TB/s HBM peak;
+  "kernels":      the same figure for each kernel class (SpMM, fused forward, fused backward);
+  "cpu_baseline": the operator-for-operator PyTorch-CPU port of the reference (oracle/rwnn_torch_port.py)
+                  timed on this host on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="proteins1024")
+    ap.add_argument("--scale", type=int, default=1, help="multiply the number of graphs per batch")
+    ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
+                    help="replay the step from a captured HIP graph (default) or launch it eagerly")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--cpu-sample-graphs", type=int, default=128)
+    return ap.parse_args()
+
+
+class Trainer:
+    """The reference's train() closure, with the gradients in one flat bucket."""
+
+    def __init__(self, model, batch_t, world):
+        from gnn_amd.dp import FlatGradBucket
+        self.model = model
+        self.adj, self.feats, self.gi, self.y = batch_t
+        self.bucket = FlatGradBucket(model)
+        self.world = world
+        self.opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True, foreach=True)
+        self.loss = None
+        self.g_fb = None
+        self.g_opt = None
+
+    def fwd_bwd(self):
+        self.bucket.zero()
+        out = self.model(self.adj, self.feats, self.gi)
+        self.loss = F.cross_entropy(out, self.y)
+        self.loss.backward()
+
+    def step_eager(self):
+        self.fwd_bwd()
+        if self.world > 1:
+            self.bucket.all_reduce()
+        self.opt.step()
+
+    def capture(self):
+        """Capture forward+backward and the Adam update as two HIP graphs; the (tiny) gradient all-reduce
+        between them stays an ordinary RCCL call on the same stream."""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                self.step_eager()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fb):
+            self.fwd_bwd()
+        self.g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_opt):
+            self.opt.step()
+
+    def step_graph(self):
+        self.g_fb.replay()
+        if self.world > 1:
+            self.bucket.all_reduce()
+        self.g_opt.replay()
+
+
+def time_kernels(model, batch_t, hp, iters=50):
+    """Average launch duration of each hand-written kernel class, by launching it back to back through the
+    C ABI between two events on the launch stream, and its algorithmic HBM bytes."""
+    from gnn_amd import _lib, get_structure
+    from gnn_amd.function import choose_stream_len
+    lib = _lib.load()
+    adj, feats, gi, _ = batch_t
+    dev = feats.device
+    st = get_structure(adj, gi)
+    n, g = st.n, st.n_graphs
+    h, s, d, steps = hp["hidden_graphs"], hp["size_hidden_graphs"], hp["hidden_dim"], hp["max_step"]
+    p = float(hp["dropout"])
+    stream = _lib.current_stream(dev)
+    xs = torch.rand((steps, n, d), device=dev)
+    z = torch.rand((steps, h, s, d), device=dev)
+    dk = torch.randn((g, steps * h), device=dev)
+    rng = torch.tensor([12345, 7], dtype=torch.int64, device=dev)
+    stream_len = choose_stream_len(n, h)
+    n_streams = lib.rwk_fused_n_streams(n, stream_len)
+    k_part = torch.empty(lib.rwk_fused_k_partials_size(n, stream_len, g, h, steps), device=dev)
+    n_part = lib.rwk_fused_dz_partials_count(n, stream_len, d, h, s, steps)
+    dz_part = torch.empty((n_part, steps, h, s, d), device=dev)
+    dx = torch.empty_like(xs)
+    y = torch.empty((n, d), device=dev)
+
+    def run_spmm():
+        st.spmm(xs[0], y)
+
+    def run_fwd():
+        _lib.check(lib.rwk_fused_forward(xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm), n, d, h,
+                                         s, steps, stream_len, p, rng.data_ptr(), k_part.data_ptr(), stream), "fwd")
+
+    def run_bwd():
+        _lib.check(lib.rwk_fused_backward(xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm),
+                                          dk.data_ptr(), st.counts_f32.data_ptr(), n, d, h, s, steps, stream_len, p,
+                                          0, rng.data_ptr(), dx.data_ptr(), dz_part.data_ptr(), stream), "bwd")
+
+    lh = steps * h
+    bytes_ = {
+        "spmm_csr": st.spmm_bytes(d),
+        "fused_forward": steps * n * d * 4 + n * 4 + (n_streams + g) * lh * 4 + steps * h * s * d * 4,
+        "fused_backward": 2 * steps * n * d * 4 + n * 4 + g * lh * 4 + n_part * steps * h * s * d * 4,
+    }
+    flops = {
+        "spmm_csr": 2 * st.nnz * d,
+        "fused_forward": 2 * h * s * d * n * steps + 3 * steps * h * s * n,
+        "fused_backward": 3 * 2 * h * s * d * n * steps + 8 * steps * h * s * n,
+    }
+    out = {}
+    for name, fn in (("spmm_csr", run_spmm), ("fused_forward", run_fwd), ("fused_backward", run_bwd)):
+        for _ in range(5):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        gbs = bytes_[name] / (us * 1e-6) / 1e9
+        out[name] = {"us": round(us, 3), "bytes": int(bytes_[name]), "GB/s": round(gbs, 1),
+                     "frac_hbm": round(gbs / HBM_PEAK_GBS, 4),
+                     "TFLOP/s": round(flops[name] / (us * 1e-6) / 1e12, 3)}
+    return out
+
+
+def cpu_baseline(batch, hp, n_graphs, budget_s=20.0):
+    """Forward + backward (train mode, dropout on) of the PyTorch-CPU port on the first n_graphs graphs."""
+    from oracle import rwnn_torch_port as P
+    sub = batch.slice_graphs(0, min(n_graphs, batch.n_graphs))
+    adj, feats, gi, y = sub.to_torch("cpu")
+    adj = adj.coalesce()
+    torch.manual_seed(0)
+    h, s, d, steps = hp["hidden_graphs"], hp["size_hidden_graphs"], hp["hidden_dim"], hp["max_step"]
+    lh = h * steps
+    params = {
+        "adj_hidden": torch.empty(h, s * (s - 1) // 2).uniform_(-1, 1),
+        "features_hidden": torch.empty(h, s, d).uniform_(0, 1),
+        "fc.weight": torch.randn(d, hp["input_dim"]) * 0.5, "fc.bias": torch.zeros(d),
+        "bn.weight": torch.ones(lh), "bn.bias": torch.zeros(lh),
+        "fc1.weight": torch.randn(hp["penultimate_dim"], lh) * 0.1, "fc1.bias": torch.zeros(hp["penultimate_dim"]),
+        "fc2.weight": torch.randn(hp["n_classes"], hp["penultimate_dim"]) * 0.1,
+        "fc2.bias": torch.zeros(hp["n_classes"]),
+    }
+    for v in params.values():
+        v.requires_grad_(True)
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+
+    def step():
+        for v in params.values():
+            v.grad = None
+        out, _ = P.forward(params, adj, feats, gi, steps, hp["normalize"], hp["dropout"], True)
+        F.nll_loss(out, y).backward()
+
+    for _ in range(2):
+        step()
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 20 and (time.perf_counter() - t_start) < budget_s:
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(sub.n_graphs / med, 1), "unit": "graphs/s", "cores": threads, "kind": "port",
+            "sample": f"first {sub.n_graphs} graphs ({sub.n_nodes} nodes, {sub.nnz} nnz) of the same batch, "
+                      f"fwd+bwd train mode, median of {len(times)} steps",
+            "ms_per_step": round(med * 1e3, 2)}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from gnn_amd import RW_NN
+    from gnn_amd.dp import broadcast_parameters
+    from gnn_amd.synth import CONFIGS, config_batch
+
+    cfg = CONFIGS[args.config]
+    hp = cfg["hp"]
+    batch = config_batch(args.config, seed=1 + rank, scale=args.scale)     # each rank its own graphs
+    batch_t = batch.to_torch(dev)
+
+    torch.manual_seed(0)
+    model = RW_NN(hp["input_dim"], hp["max_step"], hp["hidden_graphs"], hp["size_hidden_graphs"], hp["hidden_dim"],
+                  hp["penultimate_dim"], hp["normalize"], hp["n_classes"], hp["dropout"], dev).to(dev)
+    model.train()
+    model.seed_dropout(1234 + rank)
+    broadcast_parameters(model)
+    tr = Trainer(model, batch_t, world)
+    if args.mode == "graph":
+        tr.capture()
+        step = tr.step_graph
+    else:
+        step = tr.step_eager
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    n_graphs_total = batch.n_graphs
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([batch.n_graphs], dtype=torch.float64, device=dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        n_graphs_total = int(c.item())
+    loss = float(tr.loss.item())
+
+    if rank == 0:
+        result = {
+            "metric": "train graphs/sec (fwd+bwd)",
+            "value": round(n_graphs_total * args.steps / elapsed, 1),
+            "unit": "graphs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.config}: {batch.n_graphs} graphs/GPU, {batch.n_nodes} nodes, {batch.nnz} nnz "
+                            f"(rank 0), H{hp['hidden_graphs']} S{hp['size_hidden_graphs']} D{hp['hidden_dim']} "
+                            f"L{hp['max_step']} dropout {hp['dropout']}",
+                "step": "zero_grad + forward + cross_entropy + backward + grad all-reduce + Adam",
+                "launch": args.mode,
+                "parallelism": f"dp{world} (graphs sharded, one flat-bucket all-reduce)",
+            },
+            "final_loss": round(loss, 5),
+        }
+        if not args.no_kernel_timing:
+            kern = time_kernels(model, batch_t, hp)
+            dom = max(kern, key=lambda k: kern[k]["us"])
+            result["kernels"] = kern
+            result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["GB/s"], "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": kern[dom]["frac_hbm"], "traffic": None}
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(batch, hp, args.cpu_sample_graphs)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

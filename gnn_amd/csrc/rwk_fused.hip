@@ -181,6 +181,9 @@ fused_forward_kernel(const float *__restrict__ x, const float *__restrict__ z, c
 
         uint32_t bits = 0;
         int cur_call = -1;
+        float node_acc[LT];                              // this node's sum over s, added to acc once
+#pragma unroll
+        for (int i = 0; i < LT; ++i) node_acc[i] = 0.f;
         for (int ss = 0; ss < s_cnt; ++ss) {
             const float *z0 = zs + ((size_t)(0 * h + hh) * s_cnt + ss) * DP;
             const float zx = dot_lds<DP>(z0, xr[0]);
@@ -198,9 +201,11 @@ fused_forward_kernel(const float *__restrict__ x, const float *__restrict__ z, c
                     }
                     prod = ((bits >> (e - call * 15)) & 1u) ? prod : 0.f;
                 }
-                acc[i] += prod;
+                node_acc[i] += prod;
             }
         }
+#pragma unroll
+        for (int i = 0; i < LT; ++i) acc[i] += node_acc[i];
     }
     if (lane_h < h) {
         float *dst = k_partials + (size_t)(c + g_cur) * lh + lane_h;

@@ -1,0 +1,83 @@
+"""Graph-sharded data parallelism: one process per GPU, parameters replicated, ONE gradient all-reduce per step.
+
+Graphs of a batch are independent (block-diagonal adjacency; row g of the kernel features depends on
+graph g only), so a batch shards by contiguous ranges of graphs with no collective in the data path.
+The only exchange is the gradient sum over a single flat fp32 bucket (about 1.7k floats for the default
+hyper-parameters, 49k for 64 hidden graphs of 10 nodes at hidden_dim 64): a latency-bound message, so it
+is issued as one RCCL all-reduce rather than per-parameter or bucketed-and-overlapped calls.
+
+The reference has no multi-device path; batch-norm statistics stay per rank.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+__all__ = ["shard_ranges", "FlatGradBucket", "broadcast_parameters"]
+
+
+def shard_ranges(weights: Sequence[int], world_size: int) -> List[Tuple[int, int]]:
+    """Split graphs 0..G-1 into ``world_size`` contiguous ranges of nearly equal total weight
+    (weight = nodes or edges per graph).  Every range is non-empty when G >= world_size."""
+    w = np.asarray(weights, dtype=np.float64)
+    g = w.size
+    if world_size < 1:
+        raise ValueError("world_size must be positive")
+    if g < world_size:
+        raise ValueError(f"cannot shard {g} graphs over {world_size} ranks")
+    csum = np.concatenate([[0.0], np.cumsum(w)])
+    bounds = [0]
+    for r in range(1, world_size):
+        target = csum[-1] * r / world_size
+        cut = int(np.searchsorted(csum, target, side="left"))
+        cut = max(cut, bounds[-1] + 1)              # non-empty
+        cut = min(cut, g - (world_size - r))        # leave one graph for each later rank
+        bounds.append(cut)
+    bounds.append(g)
+    return [(bounds[i], bounds[i + 1]) for i in range(world_size)]
+
+
+class FlatGradBucket:
+    """All parameter gradients of a module as views into one contiguous fp32 buffer.
+
+    ``p.grad`` of every parameter aliases a slice of ``self.flat``; autograd accumulates into those views
+    in place, ``zero()`` clears the buffer with one fill and ``all_reduce()`` issues one collective.
+    """
+
+    def __init__(self, module: torch.nn.Module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError("module has no trainable parameters")
+        dev, dtype = self.params[0].device, self.params[0].dtype
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=dtype, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce(self, group=None, average: bool = True):
+        """Sum (or mean) of the bucket over the ranks of ``group``; a no-op for a single process."""
+        if not dist.is_available() or not dist.is_initialized():
+            return
+        world = dist.get_world_size(group)
+        if world == 1:
+            return
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            self.flat.div_(world)
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None):
+    """Make every rank start from rank ``src``'s parameters and buffers."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)

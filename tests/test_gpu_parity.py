@@ -106,7 +106,10 @@ def test_layer_forward_backward(name, dev):
     else:
         assert m.adj_hidden.grad is None
     for key in want:
-        assert rel_err(got[key].cpu().numpy(), want[key]) < TOL, key
+        # Where cancellation over the nodes keeps even the reference's own float32 gradient further than
+        # 1e-5 from the float64 truth, we must be at least as accurate as the reference is.
+        ref_own_err = rel_err(c.grads[key], want[key])
+        assert rel_err(got[key].cpu().numpy(), want[key]) < max(TOL, ref_own_err), key
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -124,12 +127,37 @@ def test_full_model_against_reference(name, dev):
     loss.backward()
     assert rel_err(out.detach().cpu().numpy(), c["out"]) < 1e-4
     assert abs(float(loss) - float(c["loss"])) < 1e-4 * max(1.0, abs(float(c["loss"])))
-    tol = 5e-2 if c.train else 1e-4
     grads = {n: p.grad for n, p in m.named_parameters()}
     grads["features"] = feats.grad
+    truth = _float64_port_grads(c)
     for key, ref in c.grads.items():
         assert grads[key] is not None, key
-        assert rel_err(grads[key].cpu().numpy(), ref) < tol, key
+        ref_own_err = rel_err(ref, truth[key])
+        # torch's own train-mode batch-norm differs by 1.2e-4 between its CPU and GPU kernels on the
+        # reference's K (x - mean cancels 3-4 digits), before any of our code is involved; the tight
+        # checks of the HIP kernels are test_layer_forward_backward and test_dropout_mask_replay
+        floor = 5e-3 if c.train else 1e-4
+        got = grads[key].cpu().numpy()
+        tiny = float(np.max(np.abs(got - truth[key]))) < 2e-6        # e.g. fc2.bias: entries cancel to ~1e-3
+        assert tiny or rel_err(got, truth[key]) < max(floor, 10 * ref_own_err), key
+
+
+def _float64_port_grads(c):
+    """Gradients of the whole model in float64 on the CPU (operator-for-operator port of the reference)."""
+    from oracle import rwnn_torch_port as P
+    adj, feats, gi, y = c.torch_inputs(dtype=torch.float64)
+    params = P.cast_params(c.torch_state(), torch.float64, requires_grad=True)
+    feats = feats.clone().requires_grad_(True)
+    bn_stats = None
+    if not c.train:
+        bn_stats = (torch.from_numpy(c.params["bn.running_mean"]).double(),
+                    torch.from_numpy(c.params["bn.running_var"]).double())
+    out, _ = P.forward(params, adj, feats, gi, c.hp["max_step"], c.hp["normalize"], c.hp["dropout"], c.train,
+                       bn_stats)
+    F.nll_loss(out, y).backward()
+    grads = {n: p.grad.numpy() for n, p in params.items() if p.grad is not None}
+    grads["features"] = feats.grad.numpy()
+    return grads
 
 
 def test_backward_is_bitwise_reproducible(dev):
@@ -169,7 +197,7 @@ def test_dropout_mask_replay(name, p, dev):
     keep = keep_dev.cpu().numpy().astype(bool)
     keep_ref = O.dropout_keep(seed, offset, c.n_nodes, h, s, steps, p)
     assert np.array_equal(keep, keep_ref)
-    assert abs(keep.mean() - (1 - p)) < 0.02
+    assert abs(keep.mean() - (1 - p)) < 5 * np.sqrt(p * (1 - p) / keep.size) + 2e-5
 
     pre = m.fc(feats)
     k = rw_kernel_layer(pre, m.adj_hidden, m.features_hidden, st, steps, bool(hp["normalize"]), p, rng)
