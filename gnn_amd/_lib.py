@@ -35,6 +35,11 @@ SIGNATURES = {
     "rwk_fused_reduce": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, c_float, c_int, _P, _P]),
     "rwk_fused_backward": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_float, c_int,
                                    _P, _P, _P, _P]),
+    "rwk_project_forward": (c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
+    "rwk_project_backward_blocks": (_I64, [_I64, _I64]),
+    "rwk_project_backward": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P]),
+    "rwk_reduce_rows_workspace": (_I64, [_I64, _I64]),
+    "rwk_reduce_rows": (c_int, [_P, _I64, _I64, _P, _P, _P]),
     "rwk_dropout_mask": (c_int, [_P, _I64, _I64, _I64, _I64, c_float, _P, _P]),
 }
 

@@ -1,0 +1,195 @@
+// Input projection  X0 = sigmoid(features W^T + b)  (rwgnn2/model.py:43) for narrow inputs, its
+// backward, and the generic deterministic row reduction the backward kernels share.
+//
+// With F = 1 (node degree as the only feature, utils.py:24) the projection is N x 1 times 1 x D:
+// a GEMM library spends ~0.7 ms on the N-long weight-gradient reduction, the kernels here stream it
+// at HBM rate: forward reads N*F and writes N*D floats; backward reads 2*N*D + N*F floats and
+// writes per-workgroup partial sums of (dW | db) which rwk_reduce_rows adds in a fixed order.
+#include "rwk_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// one thread per (node, output channel)
+__global__ void __launch_bounds__(kBlock)
+project_forward_kernel(const float *__restrict__ feat, const float *__restrict__ w, const float *__restrict__ b,
+                       long long n, int f, int d, float *__restrict__ x0) {
+    const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n * d) return;
+    const long long node = t / d;
+    const int c = (int)(t % d);
+    float acc = b[c];
+    const float *fr = feat + node * f;
+    const float *wr = w + (size_t)c * f;
+    for (int k = 0; k < f; ++k) acc = fmaf(fr[k], wr[k], acc);
+    x0[t] = 1.0f / (1.0f + expf(-acc));
+}
+
+// Thread (slot, c): c = output channel, slot strides over nodes.  FP = padded input width.
+// partials row layout: [c * f + k] for dW (d*f values) then [d*f + c] for db.
+template <int FP>
+__global__ void __launch_bounds__(kBlock)
+project_backward_kernel(const float *__restrict__ dx0, const float *__restrict__ x0,
+                        const float *__restrict__ feat, const float *__restrict__ w, long long n, int f, int d,
+                        int dpad, float *__restrict__ partials, float *__restrict__ d_feat) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [FP + 1][kBlock]
+    const int tid = threadIdx.x;
+    const int c = tid % dpad;
+    const int slot = tid / dpad;
+    const int slots = kBlock / dpad;
+    const bool own = c < d;
+    float acc_w[FP];
+#pragma unroll
+    for (int k = 0; k < FP; ++k) acc_w[k] = 0.f;
+    float acc_b = 0.f;
+    float wr[FP];
+#pragma unroll
+    for (int k = 0; k < FP; ++k) wr[k] = (own && k < f) ? w[(size_t)c * f + k] : 0.f;
+    // uniform trip count so that the optional group sum sees every lane
+    const long long per_round = (long long)gridDim.x * slots;
+    const long long rounds = (n + per_round - 1) / per_round;
+    for (long long r = 0; r < rounds; ++r) {
+        const long long node = r * per_round + (long long)blockIdx.x * slots + slot;
+        const bool valid = node < n && own;
+        float dpre = 0.f;
+        float fr[FP];
+#pragma unroll
+        for (int k = 0; k < FP; ++k) fr[k] = 0.f;
+        if (valid) {
+            const float xv = x0[node * d + c];
+            dpre = dx0[node * d + c] * xv * (1.0f - xv);
+#pragma unroll
+            for (int k = 0; k < FP; ++k)
+                if (k < f) fr[k] = feat[node * f + k];
+        }
+        acc_b += dpre;
+#pragma unroll
+        for (int k = 0; k < FP; ++k) acc_w[k] = fmaf(dpre, fr[k], acc_w[k]);
+        if (d_feat != nullptr) {
+#pragma unroll
+            for (int k = 0; k < FP; ++k) {
+                const float v = rwk_group_sum(dpre * wr[k], dpad);
+                if (node < n && c == 0 && k < f) d_feat[node * f + k] = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < FP; ++k) lds[k * kBlock + tid] = acc_w[k];
+    lds[FP * kBlock + tid] = acc_b;
+    __syncthreads();
+    const int n_out = d * f + d;
+    float *out = partials + (size_t)blockIdx.x * n_out;
+    for (int o = tid; o < n_out; o += kBlock) {
+        int cc, row;
+        if (o < d * f) { cc = o / f; row = o % f; } else { cc = o - d * f; row = FP; }
+        float acc = 0.f;
+        for (int q = 0; q < slots; ++q) acc += lds[row * kBlock + q * dpad + cc];
+        out[o] = acc;
+    }
+}
+
+// out[v] (or partial rows) = sum over `rows_per_block` consecutive rows, rows added in index order
+__global__ void __launch_bounds__(kBlock)
+reduce_rows_kernel(const float *__restrict__ in, long long p, long long v, int rows_per_block,
+                   float *__restrict__ out) {
+    const long long col = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (col >= v) return;
+    const long long r0 = (long long)blockIdx.y * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > p) r1 = p;
+    float acc = 0.f;
+    for (long long r = r0; r < r1; ++r) acc += in[r * v + col];
+    out[(long long)blockIdx.y * v + col] = acc;
+}
+
+constexpr int kRowsPerBlock = 32;
+
+inline int pow2_ceil(int x) {
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t rwk_reduce_rows_workspace(int64_t p, int64_t v) {
+    int64_t total = 0;
+    while (p > kRowsPerBlock) {
+        p = rwk_ceil_div(p, kRowsPerBlock);
+        total += p * v;
+    }
+    return total;
+}
+
+int rwk_reduce_rows(const float *in, int64_t p, int64_t v, float *out, float *workspace, rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(in);
+    RWK_REQUIRE_PTR(out);
+    if (p <= 0 || v <= 0 || v >= 0x7FFFFFFFll * 64) return RWK_E_SIZE;
+    if (p > kRowsPerBlock) RWK_REQUIRE_PTR(workspace);
+    const float *src = in;
+    float *ws = workspace;
+    while (true) {
+        const int64_t blocks_y = rwk_ceil_div(p, kRowsPerBlock);
+        if (blocks_y > 65535) return RWK_E_SIZE;
+        float *dst = blocks_y == 1 ? out : ws;
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)rwk_ceil_div(v, kBlock), (unsigned)blocks_y),
+                           dim3(kBlock), 0, (hipStream_t)stream, src, (long long)p, (long long)v, kRowsPerBlock, dst);
+        RWK_LAUNCH_CHECK();
+        if (blocks_y == 1) return RWK_OK;
+        src = dst;
+        ws += blocks_y * v;
+        p = blocks_y;
+    }
+}
+
+int rwk_project_forward(const float *features, const float *weight, const float *bias, int64_t n, int64_t f,
+                        int64_t d, float *x0, rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(features);
+    RWK_REQUIRE_PTR(weight);
+    RWK_REQUIRE_PTR(bias);
+    RWK_REQUIRE_PTR(x0);
+    if (n <= 0 || f <= 0 || d <= 0 || n * d >= 0x7FFFFFFFll * kBlock) return RWK_E_SIZE;
+    hipLaunchKernelGGL(project_forward_kernel, dim3((unsigned)rwk_ceil_div(n * d, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, features, weight, bias, (long long)n, (int)f, (int)d, x0);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
+int64_t rwk_project_backward_blocks(int64_t n, int64_t d) {
+    if (n <= 0 || d <= 0 || d > 64) return 0;
+    const int64_t slots = kBlock / pow2_ceil((int)d);
+    int64_t blocks = rwk_ceil_div(n, slots * 8);       // about 8 nodes per thread
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    return blocks;
+}
+
+int rwk_project_backward(const float *dx0, const float *x0, const float *features, const float *weight,
+                         int64_t n, int64_t f, int64_t d, float *partials, float *d_features,
+                         rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(dx0);
+    RWK_REQUIRE_PTR(x0);
+    RWK_REQUIRE_PTR(features);
+    RWK_REQUIRE_PTR(weight);
+    RWK_REQUIRE_PTR(partials);
+    if (n <= 0 || f <= 0 || d <= 0) return RWK_E_SIZE;
+    if (f > 8 || d > 64) return RWK_E_UNSUPPORTED;
+    const int dpad = pow2_ceil((int)d);
+    const unsigned blocks = (unsigned)rwk_project_backward_blocks(n, d);
+    hipStream_t s = (hipStream_t)stream;
+#define RWK_PB(FP)                                                                                              \
+    hipLaunchKernelGGL((project_backward_kernel<FP>), dim3(blocks), dim3(kBlock), (FP + 1) * kBlock * sizeof(float), s, \
+                       dx0, x0, features, weight, (long long)n, (int)f, (int)d, dpad, partials, d_features)
+    if (f == 1) RWK_PB(1);
+    else if (f == 2) RWK_PB(2);
+    else if (f <= 4) RWK_PB(4);
+    else RWK_PB(8);
+#undef RWK_PB
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
+}  // extern "C"

@@ -1,11 +1,16 @@
 """``torch.autograd.Function`` around the HIP kernels of the random-walk-kernel layer.
 
-Replaces ``rwgnn2/model.py:43-67`` (sigmoid of the input projection, the ``max_step``-step
-propagation on the batch graph and on the hidden graphs, the (H*S) x N contraction, dropout,
-product, per-graph segment sum, normalisation and concatenation) and their autograd backward.
+Replaces ``rwgnn2/model.py:43-67`` (input projection + sigmoid, the ``max_step``-step propagation on the
+batch graph and on the hidden graphs, the (H*S) x N contraction, dropout, product, per-graph segment
+sum, normalisation and concatenation) and their autograd backward.
 
-Launch count per call: forward 3 + (L-1) kernels (+1 sigmoid), backward 2 + (L-1) (+ the sigmoid
-derivative).  All buffers are torch tensors; the library itself allocates nothing.
+Two entry modes:
+* narrow inputs (``input_dim <= 8``, e.g. the node degree): the projection ``features @ W^T + b`` and its
+  weight/bias gradients run in our own streaming kernels (a GEMM library spends ~0.7 ms on the N-long
+  reduction of a 4 x N by N x 1 product);
+* wide inputs: the caller applies ``fc`` with torch (a real GEMM) and passes the pre-activation.
+
+All buffers are torch tensors; the library itself allocates nothing.
 """
 from __future__ import annotations
 
@@ -14,7 +19,9 @@ import torch
 from . import _lib
 from .structure import GraphStructure
 
-__all__ = ["rw_kernel_layer", "choose_stream_len"]
+__all__ = ["rw_kernel_layer", "rw_kernel_layer_projected", "choose_stream_len", "FUSED_PROJECTION_MAX_INPUT_DIM"]
+
+FUSED_PROJECTION_MAX_INPUT_DIM = 8
 
 # lanes we want in flight: 256 CUs x 4 SIMDs x 4 wavefronts x 64 lanes
 _TARGET_LANES = 256 * 4 * 4 * 64
@@ -34,18 +41,32 @@ def choose_stream_len(n_nodes: int, n_hidden: int) -> int:
     return max(16, min(512, want))
 
 
+def _reduce_rows(lib, partials2d, stream):
+    """Deterministic column sum of a (P, V) tensor."""
+    p, v = partials2d.shape
+    out = torch.empty(v, dtype=torch.float32, device=partials2d.device)
+    ws_n = lib.rwk_reduce_rows_workspace(p, v)
+    ws = torch.empty(max(ws_n, 1), dtype=torch.float32, device=partials2d.device)
+    _lib.check(lib.rwk_reduce_rows(partials2d.data_ptr(), p, v, out.data_ptr(), ws.data_ptr(), stream),
+               "rwk_reduce_rows")
+    return out
+
+
 class _RWKernelLayer(torch.autograd.Function):
+    """inp is the pre-activation (N, D) when fc_weight is None, else the raw features (N, F)."""
+
     @staticmethod
-    def forward(ctx, pre, adj_hidden, features_hidden, st: GraphStructure, max_step: int, normalize: bool,
-                drop_p: float, rng_state):
+    def forward(ctx, inp, fc_weight, fc_bias, adj_hidden, features_hidden, st: GraphStructure, max_step: int,
+                normalize: bool, drop_p: float, rng_state):
         lib = _lib.load()
-        if not pre.is_cuda:
+        if not inp.is_cuda:
             raise RuntimeError("gnn_amd runs on HIP devices only (no CPU fallback)")
-        dev = pre.device
+        dev = inp.device
         n_hidden, s, d = features_hidden.shape
         n, g, steps = st.n, st.n_graphs, int(max_step)
-        if pre.shape != (n, d):
-            raise ValueError(f"projected features have shape {tuple(pre.shape)}, expected {(n, d)}")
+        projected = fc_weight is not None
+        if inp.shape[0] != n or (not projected and inp.shape[1] != d):
+            raise ValueError(f"input has shape {tuple(inp.shape)} for {n} nodes and hidden_dim {d}")
         if n_hidden > 64 or d > 64 or steps > 4:
             raise NotImplementedError(
                 "the HIP kernels cover hidden_graphs <= 64, hidden_dim <= 64, max_step <= 4 "
@@ -56,7 +77,15 @@ class _RWKernelLayer(torch.autograd.Function):
             adj_hidden_c = adj_hidden.detach().contiguous()
             feat_c = features_hidden.detach().contiguous()
             xs = torch.empty((steps, n, d), dtype=torch.float32, device=dev)
-            torch.sigmoid(pre.detach(), out=xs[0])                              # model.py:43
+            inp_c = inp.detach().contiguous()
+            w_c = None
+            if projected:                                                        # model.py:43
+                w_c = fc_weight.detach().contiguous()
+                _lib.check(lib.rwk_project_forward(inp_c.data_ptr(), w_c.data_ptr(),
+                                                   fc_bias.detach().contiguous().data_ptr(), n, inp_c.shape[1], d,
+                                                   xs.data_ptr(), stream), "rwk_project_forward")
+            else:
+                torch.sigmoid(inp_c, out=xs[0])
             z = torch.empty((steps, n_hidden, s, d), dtype=torch.float32, device=dev)
             ah = torch.empty((n_hidden, s, s), dtype=torch.float32, device=dev)
             rng_used = torch.empty(2, dtype=torch.int64, device=dev) if drop else None
@@ -77,17 +106,17 @@ class _RWKernelLayer(torch.autograd.Function):
                                             st.counts_f32.data_ptr(), g, n_hidden, steps, stream_len, drop,
                                             int(bool(normalize)), k.data_ptr(), stream), "rwk_fused_reduce")
         ctx.st = st
-        ctx.cfg = (steps, bool(normalize), drop, stream_len)
-        ctx.save_for_backward(xs, z, ah, adj_hidden_c, rng_used)
+        ctx.cfg = (steps, bool(normalize), drop, stream_len, projected)
+        ctx.save_for_backward(xs, z, ah, adj_hidden_c, rng_used, inp_c if projected else None, w_c)
         return k
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, d_k):
         lib = _lib.load()
-        xs, z, ah, adj_hidden_c, rng_used = ctx.saved_tensors
+        xs, z, ah, adj_hidden_c, rng_used, feats, w_c = ctx.saved_tensors
         st: GraphStructure = ctx.st
-        steps, normalize, drop, stream_len = ctx.cfg
+        steps, normalize, drop, stream_len, projected = ctx.cfg
         _, n_hidden, s, d = z.shape
         n = st.n
         dev = xs.device
@@ -98,7 +127,7 @@ class _RWKernelLayer(torch.autograd.Function):
             n_part = lib.rwk_fused_dz_partials_count(n, stream_len, d, n_hidden, s, steps)
             if n_part <= 0:
                 raise NotImplementedError("unsupported hyper-parameters for the fused backward kernel")
-            dz_partials = torch.empty((n_part, steps, n_hidden, s, d), dtype=torch.float32, device=dev)
+            dz_partials = torch.empty((n_part, steps * n_hidden * s * d), dtype=torch.float32, device=dev)
             _lib.check(lib.rwk_fused_backward(xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm),
                                               d_k.data_ptr(), st.counts_f32.data_ptr(), n, d, n_hidden, s, steps,
                                               stream_len, drop, int(normalize), _lib.ptr(rng_used),
@@ -106,21 +135,44 @@ class _RWKernelLayer(torch.autograd.Function):
                        "rwk_fused_backward")
             for i in range(steps - 1, 0, -1):
                 st.spmm(dx[i], dx[i - 1], transpose=True, accumulate=True)      # dX[i-1] += A^T dX[i]
+            dz = _reduce_rows(lib, dz_partials, stream)
             d_adj = torch.empty_like(adj_hidden_c)
             d_feat = torch.empty((n_hidden, s, d), dtype=torch.float32, device=dev)
             _lib.check(lib.rwk_hidden_backward(_lib.ptr(adj_hidden_c), ah.data_ptr(), z.data_ptr(),
-                                               dz_partials.data_ptr(), n_part, n_hidden, s, d, steps,
+                                               dz.data_ptr(), 1, n_hidden, s, d, steps,
                                                _lib.ptr(d_adj), d_feat.data_ptr(), stream),
                        "rwk_hidden_backward")
             x0 = xs[0]
-            d_pre = dx[0] * x0 * (1.0 - x0)                                      # sigmoid'
+            d_w = d_b = None
+            if projected:
+                f = feats.shape[1]
+                blocks = lib.rwk_project_backward_blocks(n, d)
+                partials = torch.empty((blocks, d * f + d), dtype=torch.float32, device=dev)
+                d_inp = torch.empty_like(feats) if ctx.needs_input_grad[0] else None
+                _lib.check(lib.rwk_project_backward(dx.data_ptr(), x0.data_ptr(), feats.data_ptr(), w_c.data_ptr(),
+                                                    n, f, d, partials.data_ptr(), _lib.ptr(d_inp), stream),
+                           "rwk_project_backward")
+                wb = _reduce_rows(lib, partials, stream)
+                d_w = wb[:d * f].view(d, f)
+                d_b = wb[d * f:]
+            else:
+                d_inp = dx[0] * x0 * (1.0 - x0)                                  # sigmoid'
         # with a single step adj_hidden never enters the forward pass: the reference leaves its
         # .grad at None, and so do we
-        return d_pre, (d_adj if steps > 1 else None), d_feat, None, None, None, None, None
+        return d_inp, d_w, d_b, (d_adj if steps > 1 else None), d_feat, None, None, None, None, None
 
 
 def rw_kernel_layer(pre, adj_hidden, features_hidden, structure: GraphStructure, max_step: int,
                     normalize: bool, drop_p: float = 0.0, rng_state=None):
     """(G, max_step*H) random-walk-kernel features; ``pre`` is ``fc(features)`` BEFORE the sigmoid."""
-    return _RWKernelLayer.apply(pre, adj_hidden, features_hidden, structure, max_step, normalize, drop_p,
-                                rng_state)
+    return _RWKernelLayer.apply(pre, None, None, adj_hidden, features_hidden, structure, max_step, normalize,
+                                drop_p, rng_state)
+
+
+def rw_kernel_layer_projected(features, fc_weight, fc_bias, adj_hidden, features_hidden,
+                              structure: GraphStructure, max_step: int, normalize: bool, drop_p: float = 0.0,
+                              rng_state=None):
+    """Same, with the input projection ``sigmoid(features @ fc_weight.T + fc_bias)`` fused in
+    (``features.shape[1] <= FUSED_PROJECTION_MAX_INPUT_DIM``)."""
+    return _RWKernelLayer.apply(features, fc_weight, fc_bias, adj_hidden, features_hidden, structure, max_step,
+                                normalize, drop_p, rng_state)

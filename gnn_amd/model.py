@@ -13,7 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.parameter import Parameter
 
-from .function import rw_kernel_layer
+from .function import FUSED_PROJECTION_MAX_INPUT_DIM, rw_kernel_layer, rw_kernel_layer_projected
 from .structure import get_structure
 
 __all__ = ["RW_NN"]
@@ -60,28 +60,32 @@ class RW_NN(nn.Module):
         structure = get_structure(adj, graph_indicator)
         p = float(self.dropout.p)
         drop = p if self.training else 0.0
-        pre = self.fc(features)
         if drop >= 1.0:
             # every product is dropped (model.py:58 with p = 1): K is exactly zero
+            pre = self.fc(features)
             k = pre.new_zeros(structure.n_graphs, self.hidden_graphs * self.max_step)
             k = k + 0.0 * (pre.sum() + self.features_hidden.sum() + self.adj_hidden.sum())
         else:
-            if drop > 0.0 and not self._rng_seeded:
-                self.seed_dropout(int(torch.randint(0, 2 ** 62, (1,)).item()))
-            k = rw_kernel_layer(pre, self.adj_hidden, self.features_hidden, structure, self.max_step,
-                                bool(self.normalize), drop, self._rng_state if drop > 0.0 else None)
+            k = self._rw(features, structure, drop)
         out = self.bn(k)
         out = self.relu(self.fc1(out))
         out = self.dropout(out)
         out = self.fc2(out)
         return F.log_softmax(out, dim=1)
 
+    def _rw(self, features, structure, drop):
+        if drop > 0.0 and not self._rng_seeded:
+            self.seed_dropout(int(torch.randint(0, 2 ** 62, (1,)).item()))
+        rng = self._rng_state if drop > 0.0 else None
+        if features.shape[1] <= FUSED_PROJECTION_MAX_INPUT_DIM:
+            return rw_kernel_layer_projected(features, self.fc.weight, self.fc.bias, self.adj_hidden,
+                                             self.features_hidden, structure, self.max_step,
+                                             bool(self.normalize), drop, rng)
+        return rw_kernel_layer(self.fc(features), self.adj_hidden, self.features_hidden, structure,
+                               self.max_step, bool(self.normalize), drop, rng)
+
     def rw_features(self, adj, features, graph_indicator):
         """The (G, max_step*H) input of ``bn`` (model.py:67), for tests and benchmarks."""
         structure = get_structure(adj, graph_indicator)
         drop = float(self.dropout.p) if self.training else 0.0
-        if drop > 0.0 and not self._rng_seeded:
-            self.seed_dropout(int(torch.randint(0, 2 ** 62, (1,)).item()))
-        return rw_kernel_layer(self.fc(features), self.adj_hidden, self.features_hidden, structure,
-                               self.max_step, bool(self.normalize), drop,
-                               self._rng_state if drop > 0.0 else None)
+        return self._rw(features, structure, drop)

@@ -159,6 +159,32 @@ int rwk_fused_backward(const float *x, const float *z, const int32_t *gid, const
                        int normalize, const uint64_t *rng, float *dx, float *dz_partials,
                        rwk_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Input projection  X0 = sigmoid(features W^T + b)   replaces model.py:43 for narrow inputs
+ * (input_dim <= 8; wider inputs go through a GEMM library and only the sigmoid is applied here)
+ * ------------------------------------------------------------------------------------- */
+
+/* features (n, f), weight (d, f), bias (d) -> x0 (n, d). */
+int rwk_project_forward(const float *features, const float *weight, const float *bias, int64_t n,
+                        int64_t f, int64_t d, float *x0, rwk_stream_t stream);
+
+/* Workgroups rwk_project_backward launches = rows of its `partials` output (host side, pure). */
+int64_t rwk_project_backward_blocks(int64_t n, int64_t d);
+
+/* dx0 (n, d): gradient of x0.  partials (blocks, d*f + d): per-workgroup sums of
+ * [dW (d, f) | db (d)], to be added row by row with rwk_reduce_rows.  d_features (n, f) is
+ * written when non-null.  Requires f <= 8, d <= 64. */
+int rwk_project_backward(const float *dx0, const float *x0, const float *features,
+                         const float *weight, int64_t n, int64_t f, int64_t d, float *partials,
+                         float *d_features, rwk_stream_t stream);
+
+/* out[v] = sum_p in[p, v], rows added in a fixed tree order (32 consecutive rows per level),
+ * so the result is bitwise reproducible.  workspace: rwk_reduce_rows_workspace(p, v) floats
+ * (0 when p <= 32). */
+int64_t rwk_reduce_rows_workspace(int64_t p, int64_t v);
+int rwk_reduce_rows(const float *in, int64_t p, int64_t v, float *out, float *workspace,
+                    rwk_stream_t stream);
+
 /* Test hook: writes the keep-mask exactly as the fused kernels draw it, one byte per element,
  * shape (L, H, S, N), for the {seed, offset} in rng. */
 int rwk_dropout_mask(const uint64_t *rng, int64_t n, int64_t h, int64_t s, int64_t max_step,
