@@ -18,6 +18,7 @@
 // HBM bytes per call (roofline figure): forward  L*N*D*4 + N*4 (+ N*4 with perm) + slots*L*H*4;
 //                                        backward 2*L*N*D*4 + N*4 + G*L*H*4 + partials.
 #include "rwk_common.h"
+#include "rwk_fused_reg.h"
 
 namespace {
 
@@ -525,6 +526,7 @@ int64_t rwk_fused_dz_partials_count(int64_t n, int64_t stream_len, int64_t d, in
                                     int64_t max_step) {
     FusedPlan plan;
     if (!sizes_ok(n, d, h, s, max_step, stream_len)) return 0;
+    if (rwk_reg::supported(d, h, s, max_step)) return rwk_reg::backward_blocks(n, stream_len, h);
     if (!plan_for(n, d, h, s, max_step, stream_len, true, &plan)) return 0;
     return plan.n_blocks;
 }
@@ -538,6 +540,15 @@ int rwk_fused_forward(const float *x, const float *z, const int32_t *gid, const 
     RWK_REQUIRE_PTR(k_partials);
     if (!sizes_ok(n, d, h, s, max_step, stream_len) || !(drop_p >= 0.f && drop_p < 1.f)) return RWK_E_SIZE;
     const bool drop = drop_p > 0.f && rng != nullptr;
+    if (rwk_reg::supported(d, h, s, max_step)) {
+        rwk_reg::Args r{};
+        r.x = x; r.z = z; r.gid = gid; r.perm = perm;
+        r.n = (int)n; r.d = (int)d; r.h = (int)h; r.s = (int)s; r.max_step = (int)max_step;
+        r.stream_len = (int)stream_len; r.drop = drop; r.rng = (const unsigned long long *)rng;
+        r.stream = (hipStream_t)stream; r.k_partials = k_partials;
+        rwk_drop_thresholds(drop_p, &r.t0, &r.t1);
+        return rwk_reg::forward(r);
+    }
     FusedPlan plan;
     if (!plan_for(n, d, h, s, max_step, stream_len, false, &plan)) return RWK_E_UNSUPPORTED;
     FwdArgs a{x, z, gid, perm, (int)n, (int)d, (int)h, (int)s, (int)stream_len, {0, 0},
@@ -584,6 +595,17 @@ int rwk_fused_backward(const float *x, const float *z, const int32_t *gid, const
     if (normalize) RWK_REQUIRE_PTR(counts_f32);
     if (!sizes_ok(n, d, h, s, max_step, stream_len) || !(drop_p >= 0.f && drop_p < 1.f)) return RWK_E_SIZE;
     const bool drop = drop_p > 0.f && rng != nullptr;
+    if (rwk_reg::supported(d, h, s, max_step)) {
+        rwk_reg::Args r{};
+        r.x = x; r.z = z; r.gid = gid; r.perm = perm;
+        r.n = (int)n; r.d = (int)d; r.h = (int)h; r.s = (int)s; r.max_step = (int)max_step;
+        r.stream_len = (int)stream_len; r.drop = drop; r.rng = (const unsigned long long *)rng;
+        r.stream = (hipStream_t)stream; r.d_k = d_k; r.counts_f32 = counts_f32;
+        r.scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f; r.normalize = normalize;
+        r.dx = dx; r.dz_partials = dz_partials;
+        rwk_drop_thresholds(drop_p, &r.t0, &r.t1);
+        return rwk_reg::backward(r);
+    }
     FusedPlan plan;
     if (!plan_for(n, d, h, s, max_step, stream_len, true, &plan)) return RWK_E_UNSUPPORTED;
     BwdArgs a{x, z, gid, perm, d_k, counts_f32, (int)n, (int)d, (int)h, (int)s, (int)stream_len,

@@ -1,0 +1,32 @@
+// Register-resident variant of the fused random-walk kernels (hidden_dim <= 4, common hidden-graph sizes).
+#pragma once
+
+#include "rwk_common.h"
+
+namespace rwk_reg {
+
+struct Args {
+    const float *x, *z;            // (L,N,D), (L,H,S,D)
+    const int *gid, *perm;
+    int n, d, h, s, max_step, stream_len;
+    uint32_t t0, t1;               // dropout thresholds (rwk_drop_thresholds)
+    bool drop;
+    const unsigned long long *rng;
+    hipStream_t stream;
+    // forward
+    float *k_partials;
+    // backward
+    const float *d_k, *counts_f32;
+    float scale;
+    int normalize;
+    float *dx, *dz_partials;
+};
+
+// true when (d, h, s, max_step) has a compiled register-resident instance
+bool supported(int64_t d, int64_t h, int64_t s, int64_t max_step);
+// workgroups of the backward launch = rows of dz_partials
+int64_t backward_blocks(int64_t n, int64_t stream_len, int64_t h);
+int forward(const Args &a);
+int backward(const Args &a);
+
+}  // namespace rwk_reg

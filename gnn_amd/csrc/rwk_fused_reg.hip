@@ -1,0 +1,429 @@
+// Fused random-walk kernels, register-resident form for hidden_dim <= 4.
+//
+// Same thread layout and the same results as the generic kernels in rwk_fused.hip (a stream of
+// stream_len sorted positions per group of HP lanes, lane j = hidden graph j), but the hidden-graph
+// size S and the step count L are template parameters, so
+//   * the lane's L*S rows of Z live in registers for the whole kernel (no LDS reads in the loop),
+//   * the gradient of Z accumulates in L*S*4 registers per lane (no LDS read-modify-write per node),
+//   * every dropout sample index is a compile-time constant: one Philox4x32-10 call per 15 samples,
+//     each sample one byte compare.
+// LDS is touched once, at the end of the backward kernel, to add the lanes that own the same hidden
+// graph in a fixed order.
+#include "rwk_fused_reg.h"
+
+namespace rwk_reg {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int DP = 4;
+
+struct DropCfg {
+    uint32_t t0, t1, seed_lo, key_hi, off_lo;
+};
+
+__device__ inline DropCfg load_cfg(const unsigned long long *rng, uint32_t t0, uint32_t t1) {
+    const unsigned long long seed = rng[0], off = rng[1];
+    return DropCfg{t0, t1, (uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(off >> 32), (uint32_t)off};
+}
+
+// The keep decisions of one (node, hidden graph) stream: NC calls of 15 one-byte samples each.
+// keep(e) <=> byte < t0 + (tie byte < t1), which equals  byte < t0 || (byte == t0 && tie).
+template <int NC>
+struct Keep {
+    uint32_t w[NC][4];
+    uint32_t thr[NC];
+    __device__ inline void draw(const DropCfg &c, uint32_t node, uint32_t hq) {
+#pragma unroll
+        for (int call = 0; call < NC; ++call) {
+            const RwkPhilox4 r = rwk_philox4x32_10(node, hq, (uint32_t)call, c.off_lo, c.seed_lo, c.key_hi);
+            w[call][0] = r.x; w[call][1] = r.y; w[call][2] = r.z; w[call][3] = r.w;
+            thr[call] = c.t0 + ((r.w >> 24) < c.t1 ? 1u : 0u);
+        }
+    }
+    __device__ inline bool at(int e) const {        // e is a constant after unrolling
+        const int call = e / 15, j = e % 15;
+        return ((w[call][j >> 2] >> (8 * (j & 3))) & 0xFFu) < thr[call];
+    }
+};
+
+__device__ inline void load_x(const float *__restrict__ row, int d, float (&out)[DP]) {
+    if (d == DP) {
+        const float4 v = *reinterpret_cast<const float4 *>(row);
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+            const float v = row[k < d ? k : d - 1];     // unconditional load, then select
+            out[k] = k < d ? v : 0.f;
+        }
+    }
+}
+
+__device__ inline float dot4(const float (&a)[DP], const float (&b)[DP]) {
+    float acc = a[0] * b[0];
+    acc = fmaf(a[1], b[1], acc);
+    acc = fmaf(a[2], b[2], acc);
+    acc = fmaf(a[3], b[3], acc);
+    return acc;
+}
+
+template <int LT, int ST>
+__device__ inline void load_z(const float *__restrict__ z, int h, int hh, int d, float (&zr)[LT][ST][DP]) {
+    // every load is unconditional (a load under a per-element condition makes the compiler branch
+    // around it and wait for each one separately: L*S*4 serial round trips to L2)
+    if (d == DP) {
+#pragma unroll
+        for (int i = 0; i < LT; ++i)
+#pragma unroll
+            for (int ss = 0; ss < ST; ++ss) {
+                const float4 v = *reinterpret_cast<const float4 *>(z + (((size_t)i * h + hh) * ST + ss) * DP);
+                zr[i][ss][0] = v.x; zr[i][ss][1] = v.y; zr[i][ss][2] = v.z; zr[i][ss][3] = v.w;
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < LT; ++i)
+#pragma unroll
+            for (int ss = 0; ss < ST; ++ss)
+#pragma unroll
+                for (int k = 0; k < DP; ++k) {
+                    const float v = z[(((size_t)i * h + hh) * ST + ss) * d + (k < d ? k : d - 1)];
+                    zr[i][ss][k] = k < d ? v : 0.f;
+                }
+    }
+}
+
+// One tile = hp consecutive positions of each of the workgroup's kBlock/hp streams = kBlock node slots,
+// slot t = (stream t / hp, position t % hp): thread t loads the rows of its own slot (hp lanes read
+// hp consecutive 16-byte rows: coalesced), the tile is then read back through LDS by every lane of the
+// stream.  node[] holds the node index of the slot, or -1 past the end of the stream.
+template <int LT>
+struct Tile {
+    float4 x[LT][kBlock];
+    int gid[kBlock];
+    int node[kBlock];
+};
+
+template <int LT>
+__device__ inline void load_tile(Tile<LT> &tile, const float *__restrict__ x, const int *__restrict__ gid,
+                                 const int *__restrict__ perm, int p, bool valid, int d, size_t step_stride) {
+    const int t = threadIdx.x;
+    int node = -1, g = -1;
+    if (valid) {
+        node = perm ? perm[p] : p;
+        g = gid[p];
+    }
+    tile.node[t] = node;
+    tile.gid[t] = g;
+#pragma unroll
+    for (int i = 0; i < LT; ++i) {
+        float r[DP] = {0.f, 0.f, 0.f, 0.f};
+        if (valid) load_x(x + i * step_stride + (size_t)node * d, d, r);
+        tile.x[i][t] = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+template <int LT, int ST, bool DROP>
+__global__ void __launch_bounds__(kBlock)
+forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const int *__restrict__ gid,
+               const int *__restrict__ perm, int n, int d, int h, int stream_len, int hp, uint32_t t0, uint32_t t1,
+               const unsigned long long *__restrict__ rng, float *__restrict__ k_partials) {
+    constexpr int NC = (LT * ST + 14) / 15;
+    __shared__ Tile<LT> tile;
+    const int tid = threadIdx.x;
+    const int lane_h = tid % hp;
+    const int hh = lane_h < h ? lane_h : h - 1;
+    const int group0 = tid - lane_h;                    // first slot of this lane's stream in the tile
+    const int c = blockIdx.x * (kBlock / hp) + tid / hp;
+    const long long start_ll = (long long)c * stream_len;
+    const bool has_stream = start_ll < n;
+    const int start = has_stream ? (int)start_ll : 0;
+    const int end = has_stream ? (int)(start_ll + stream_len < n ? start_ll + stream_len : n) : 0;
+    float zr[LT][ST][DP];
+    load_z<LT, ST>(z, h, hh, d, zr);
+    DropCfg cfg;
+    if (DROP) cfg = load_cfg(rng, t0, t1);
+    const int lh = LT * h;
+    const size_t step_stride = (size_t)n * d;
+
+    float acc[LT];
+#pragma unroll
+    for (int i = 0; i < LT; ++i) acc[i] = 0.f;
+    int g_cur = -1;
+
+    for (int base = 0; base < stream_len; base += hp) {
+        __syncthreads();
+        load_tile<LT>(tile, x, gid, perm, start + base + lane_h, has_stream && start + base + lane_h < end, d,
+                      step_stride);
+        __syncthreads();
+        for (int j = 0; j < hp; ++j) {
+            const int node = tile.node[group0 + j];
+            if (node < 0) break;                          // end of this stream (uniform over the stream's lanes)
+            const int g = tile.gid[group0 + j];
+            if (g != g_cur) {
+                if (g_cur >= 0 && lane_h < h) {
+                    float *dst = k_partials + (size_t)(c + g_cur) * lh + lane_h;
+#pragma unroll
+                    for (int i = 0; i < LT; ++i) dst[i * h] = acc[i];
+                }
+#pragma unroll
+                for (int i = 0; i < LT; ++i) acc[i] = 0.f;
+                g_cur = g;
+            }
+            float xr[LT][DP];
+#pragma unroll
+            for (int i = 0; i < LT; ++i) {
+                const float4 v = tile.x[i][group0 + j];
+                xr[i][0] = v.x; xr[i][1] = v.y; xr[i][2] = v.z; xr[i][3] = v.w;
+            }
+            Keep<NC> keep;
+            if (DROP) keep.draw(cfg, (uint32_t)node, (uint32_t)lane_h);
+            float node_acc[LT];
+#pragma unroll
+            for (int i = 0; i < LT; ++i) node_acc[i] = 0.f;
+#pragma unroll
+            for (int ss = 0; ss < ST; ++ss) {
+                const float zx = dot4(zr[0][ss], xr[0]);
+#pragma unroll
+                for (int i = 0; i < LT; ++i) {
+                    const float t = i == 0 ? zx : dot4(zr[i][ss], xr[i]);
+                    float prod = zx * t;
+                    if (DROP) prod = keep.at(ss * LT + i) ? prod : 0.f;
+                    node_acc[i] += prod;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < LT; ++i) acc[i] += node_acc[i];
+        }
+    }
+    if (g_cur >= 0 && lane_h < h) {
+        float *dst = k_partials + (size_t)(c + g_cur) * lh + lane_h;
+#pragma unroll
+        for (int i = 0; i < LT; ++i) dst[i * h] = acc[i];
+    }
+}
+
+template <int LT, int ST, bool DROP>
+__global__ void __launch_bounds__(kBlock)
+backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const int *__restrict__ gid,
+                const int *__restrict__ perm, const float *__restrict__ d_k, const float *__restrict__ counts_f32,
+                int n, int d, int h, int stream_len, int hp, float scale, int normalize, uint32_t t0, uint32_t t1,
+                const unsigned long long *__restrict__ rng, float *__restrict__ dx,
+                float *__restrict__ dz_partials) {
+    constexpr int NC = (LT * ST + 14) / 15;
+    constexpr int V = LT * ST * DP;               // gradient values per lane
+    constexpr int CH = V < 32 ? V : 32;           // values staged per LDS round of the final reduction
+    __shared__ Tile<LT> tile;
+    __shared__ float red[CH][kBlock];
+
+    const int tid = threadIdx.x;
+    const int lane_h = tid % hp;
+    const int hh = lane_h < h ? lane_h : h - 1;
+    const bool own_h = lane_h < h;
+    const int group0 = tid - lane_h;
+    const int c = blockIdx.x * (kBlock / hp) + tid / hp;
+    const long long start_ll = (long long)c * stream_len;
+    const bool has_stream = start_ll < n;
+    const int start = has_stream ? (int)start_ll : 0;
+    const int end = has_stream ? (int)(start_ll + stream_len < n ? start_ll + stream_len : n) : 0;
+    float zr[LT][ST][DP];
+    load_z<LT, ST>(z, h, hh, d, zr);
+    DropCfg cfg;
+    if (DROP) cfg = load_cfg(rng, t0, t1);
+    const int lh = LT * h;
+    const size_t step_stride = (size_t)n * d;
+
+    float dz[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) dz[v] = 0.f;
+    float dp_cur[LT];
+#pragma unroll
+    for (int i = 0; i < LT; ++i) dp_cur[i] = 0.f;
+    int g_cur = -1;
+
+    for (int base = 0; base < stream_len; base += hp) {
+        const int my_p = start + base + lane_h;          // the slot this lane loads and later stores
+        const bool my_valid = has_stream && my_p < end;
+        __syncthreads();
+        load_tile<LT>(tile, x, gid, perm, my_p, my_valid, d, step_stride);
+        __syncthreads();
+        const int my_node = tile.node[tid];
+        float mine[LT][DP];                               // dX rows of this lane's own slot
+#pragma unroll
+        for (int i = 0; i < LT; ++i)
+#pragma unroll
+            for (int k = 0; k < DP; ++k) mine[i][k] = 0.f;
+        // every lane of the wavefront runs all hp iterations: the DPP butterfly needs them all
+        for (int j = 0; j < hp; ++j) {
+            const int node = tile.node[group0 + j];
+            const bool valid = node >= 0;
+            float xr[LT][DP], dxr[LT][DP];
+#pragma unroll
+            for (int i = 0; i < LT; ++i) {
+                const float4 v = tile.x[i][group0 + j];
+                xr[i][0] = v.x; xr[i][1] = v.y; xr[i][2] = v.z; xr[i][3] = v.w;
+#pragma unroll
+                for (int k = 0; k < DP; ++k) dxr[i][k] = 0.f;
+            }
+            if (valid) {
+                const int g = tile.gid[group0 + j];
+                if (g != g_cur) {
+                    g_cur = g;
+                    float f = scale;
+                    if (normalize) f /= counts_f32[g];
+#pragma unroll
+                    for (int i = 0; i < LT; ++i)
+                        dp_cur[i] = own_h ? d_k[(size_t)g * lh + i * h + lane_h] * f : 0.f;
+                }
+                Keep<NC> keep;
+                if (DROP) keep.draw(cfg, (uint32_t)node, (uint32_t)lane_h);
+#pragma unroll
+                for (int ss = 0; ss < ST; ++ss) {
+                    const float zx = dot4(zr[0][ss], xr[0]);
+                    float w[LT];
+#pragma unroll
+                    for (int i = 0; i < LT; ++i) {
+                        w[i] = dp_cur[i];
+                        if (DROP) w[i] = keep.at(ss * LT + i) ? w[i] : 0.f;
+                    }
+                    float dzx = 2.f * w[0] * zx;          // step 0 contributes keep * zx^2
+#pragma unroll
+                    for (int i = 1; i < LT; ++i) {
+                        const float t = dot4(zr[i][ss], xr[i]);
+                        dzx = fmaf(w[i], t, dzx);
+                        const float dt = w[i] * zx;
+#pragma unroll
+                        for (int k = 0; k < DP; ++k) {
+                            dxr[i][k] = fmaf(dt, zr[i][ss][k], dxr[i][k]);
+                            dz[(i * ST + ss) * DP + k] = fmaf(dt, xr[i][k], dz[(i * ST + ss) * DP + k]);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < DP; ++k) {
+                        dxr[0][k] = fmaf(dzx, zr[0][ss][k], dxr[0][k]);
+                        dz[ss * DP + k] = fmaf(dzx, xr[0][k], dz[ss * DP + k]);
+                    }
+                }
+            }
+            // sum the dX rows over the hidden graphs (the hp lanes of this stream); lane j keeps them
+#pragma unroll
+            for (int i = 0; i < LT; ++i)
+#pragma unroll
+                for (int k = 0; k < DP; ++k) {
+                    const float tot = rwk_group_sum(dxr[i][k], hp);
+                    mine[i][k] = lane_h == j ? tot : mine[i][k];
+                }
+        }
+        if (my_node >= 0) {                               // coalesced: hp lanes store hp consecutive rows
+#pragma unroll
+            for (int i = 0; i < LT; ++i) {
+                float *row = dx + i * step_stride + (size_t)my_node * d;
+                if (d == DP) {
+                    *reinterpret_cast<float4 *>(row) = make_float4(mine[i][0], mine[i][1], mine[i][2], mine[i][3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < DP; ++k)
+                        if (k < d) row[k] = mine[i][k];
+                }
+            }
+        }
+    }
+
+    // per-workgroup partial of dZ: threads that own the same hidden graph are added in thread order
+    const int spb = kBlock / hp;
+    float *out = dz_partials + (size_t)blockIdx.x * LT * h * ST * d;
+#pragma unroll
+    for (int cb = 0; cb < V; cb += CH) {
+        __syncthreads();
+#pragma unroll
+        for (int vv = 0; vv < CH; ++vv)
+            if (cb + vv < V) red[vv][tid] = dz[cb + vv];
+        __syncthreads();
+        for (int o = tid; o < CH * h; o += kBlock) {
+            const int hq = o % h, vv = o / h;
+            const int v = cb + vv;
+            if (v >= V) continue;
+            const int k = v % DP, ss = (v / DP) % ST, i = v / (DP * ST);
+            if (k >= d) continue;
+            float acc = 0.f;
+            for (int q = 0; q < spb; ++q) acc += red[vv][q * hp + hq];
+            out[(((size_t)i * h + hq) * ST + ss) * d + k] = acc;
+        }
+    }
+}
+
+inline int pow2_ceil(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+template <int LT, int ST>
+int launch_fwd(const Args &a) {
+    const int hp = pow2_ceil(a.h);
+    const int n_streams = (int)rwk_ceil_div(a.n, a.stream_len);
+    const dim3 grid((unsigned)rwk_ceil_div(n_streams, kBlock / hp));
+    if (a.drop)
+        hipLaunchKernelGGL((forward_kernel<LT, ST, true>), grid, dim3(kBlock), 0, a.stream, a.x, a.z, a.gid, a.perm,
+                           a.n, a.d, a.h, a.stream_len, hp, a.t0, a.t1, a.rng, a.k_partials);
+    else
+        hipLaunchKernelGGL((forward_kernel<LT, ST, false>), grid, dim3(kBlock), 0, a.stream, a.x, a.z, a.gid, a.perm,
+                           a.n, a.d, a.h, a.stream_len, hp, a.t0, a.t1, a.rng, a.k_partials);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
+template <int LT, int ST>
+int launch_bwd(const Args &a) {
+    const int hp = pow2_ceil(a.h);
+    const dim3 grid((unsigned)backward_blocks(a.n, a.stream_len, a.h));
+    if (a.drop)
+        hipLaunchKernelGGL((backward_kernel<LT, ST, true>), grid, dim3(kBlock), 0, a.stream, a.x, a.z, a.gid, a.perm,
+                           a.d_k, a.counts_f32, a.n, a.d, a.h, a.stream_len, hp, a.scale, a.normalize, a.t0, a.t1,
+                           a.rng, a.dx, a.dz_partials);
+    else
+        hipLaunchKernelGGL((backward_kernel<LT, ST, false>), grid, dim3(kBlock), 0, a.stream, a.x, a.z, a.gid, a.perm,
+                           a.d_k, a.counts_f32, a.n, a.d, a.h, a.stream_len, hp, a.scale, a.normalize, a.t0, a.t1,
+                           a.rng, a.dx, a.dz_partials);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
+template <int LT>
+int by_s(const Args &a, bool bwd) {
+    switch (a.s) {
+        case 3: return bwd ? launch_bwd<LT, 3>(a) : launch_fwd<LT, 3>(a);
+        case 4: return bwd ? launch_bwd<LT, 4>(a) : launch_fwd<LT, 4>(a);
+        case 5: return bwd ? launch_bwd<LT, 5>(a) : launch_fwd<LT, 5>(a);
+        case 6: return bwd ? launch_bwd<LT, 6>(a) : launch_fwd<LT, 6>(a);
+        case 8: return bwd ? launch_bwd<LT, 8>(a) : launch_fwd<LT, 8>(a);
+        case 10: return bwd ? launch_bwd<LT, 10>(a) : launch_fwd<LT, 10>(a);
+    }
+    return RWK_E_UNSUPPORTED;
+}
+
+int by_l(const Args &a, bool bwd) {
+    switch (a.max_step) {
+        case 1: return by_s<1>(a, bwd);
+        case 2: return by_s<2>(a, bwd);
+        case 3: return by_s<3>(a, bwd);
+        case 4: return by_s<4>(a, bwd);
+    }
+    return RWK_E_UNSUPPORTED;
+}
+
+}  // namespace
+
+bool supported(int64_t d, int64_t h, int64_t s, int64_t max_step) {
+    if (d < 1 || d > DP || h < 1 || h > 64 || max_step < 1 || max_step > 4) return false;
+    return s == 3 || s == 4 || s == 5 || s == 6 || s == 8 || s == 10;
+}
+
+int64_t backward_blocks(int64_t n, int64_t stream_len, int64_t h) {
+    const int hp = pow2_ceil((int)h);
+    return rwk_ceil_div(rwk_ceil_div(n, stream_len), kBlock / hp);
+}
+
+int forward(const Args &a) { return by_l(a, false); }
+int backward(const Args &a) { return by_l(a, true); }
+
+}  // namespace rwk_reg

@@ -38,7 +38,9 @@ def choose_stream_len(n_nodes: int, n_hidden: int) -> int:
     """Sorted positions walked sequentially by one lane group of the fused kernels."""
     hp = _pow2_ceil(n_hidden)
     want = -(-n_nodes * hp // _TARGET_LANES)
-    return max(16, min(512, want))
+    want = max(16, min(512, want))
+    # the kernels stage positions in tiles of hp: keep the stream a whole number of tiles
+    return hp * max(1, round(want / hp))
 
 
 def _reduce_rows(lib, partials2d, stream):

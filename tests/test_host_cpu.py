@@ -102,5 +102,6 @@ def test_spmm_schedule_rule():
 def test_stream_length_rule():
     from gnn_amd.function import choose_stream_len
     assert choose_stream_len(1168, 16) == 16
-    assert choose_stream_len(307000, 16) == 19
+    assert choose_stream_len(307000, 16) == 16
     assert choose_stream_len(50_000_000, 16) == 512
+    assert choose_stream_len(1000, 64) == 64
