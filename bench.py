@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--scale", type=int, default=1, help="multiply the number of graphs per batch")
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
                     help="replay the step from a captured HIP graph (default) or launch it eagerly")
+    ap.add_argument("--optimizer", choices=["flat", "torch"], default="flat",
+                    help="flat: gnn_amd.optim.FlatAdam (one launch); torch: torch.optim.Adam(capturable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-sample-graphs", type=int, default=128)
@@ -54,13 +56,17 @@ def parse_args():
 class Trainer:
     """The reference's train() closure, with the gradients in one flat bucket."""
 
-    def __init__(self, model, batch_t, world):
+    def __init__(self, model, batch_t, world, optimizer="flat"):
         from gnn_amd.dp import FlatGradBucket
+        from gnn_amd.optim import FlatAdam
         self.model = model
         self.adj, self.feats, self.gi, self.y = batch_t
         self.bucket = FlatGradBucket(model)
         self.world = world
-        self.opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True, foreach=True)
+        if optimizer == "flat":       # same arithmetic as torch.optim.Adam, one launch (main.py:79: lr 1e-2)
+            self.opt = FlatAdam(model, self.bucket, lr=1e-2)
+        else:
+            self.opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True, foreach=True)
         self.loss = None
         self.g_fb = None
         self.g_opt = None
@@ -241,7 +247,7 @@ def main():
     model.train()
     model.seed_dropout(1234 + rank)
     broadcast_parameters(model)
-    tr = Trainer(model, batch_t, world)
+    tr = Trainer(model, batch_t, world, args.optimizer)
     if args.mode == "graph":
         tr.capture()
         step = tr.step_graph
@@ -288,7 +294,7 @@ def main():
                 "workload": f"{args.config}: {batch.n_graphs} graphs/GPU, {batch.n_nodes} nodes, {batch.nnz} nnz "
                             f"(rank 0), H{hp['hidden_graphs']} S{hp['size_hidden_graphs']} D{hp['hidden_dim']} "
                             f"L{hp['max_step']} dropout {hp['dropout']}",
-                "step": "zero_grad + forward + cross_entropy + backward + grad all-reduce + Adam",
+                "step": "zero_grad + forward + cross_entropy + backward + grad all-reduce + Adam (%s)" % args.optimizer,
                 "launch": args.mode,
                 "parallelism": f"dp{world} (graphs sharded, one flat-bucket all-reduce)",
             },

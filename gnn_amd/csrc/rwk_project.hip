@@ -89,21 +89,37 @@ project_backward_kernel(const float *__restrict__ dx0, const float *__restrict__
     }
 }
 
-// out[v] (or partial rows) = sum over `rows_per_block` consecutive rows, rows added in index order
+// Level 1: workgroup (bx, by) owns 64 columns and the rows [by*rows_per_block, (by+1)*rows_per_block);
+// its 4 wavefronts ("slices") take every 4th row of that range, then the slices are added in slice order.
 __global__ void __launch_bounds__(kBlock)
-reduce_rows_kernel(const float *__restrict__ in, long long p, long long v, int rows_per_block,
-                   float *__restrict__ out) {
-    const long long col = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (col >= v) return;
+reduce_rows_level1_kernel(const float *__restrict__ in, long long p, long long v, int rows_per_block,
+                          float *__restrict__ out) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const long long col = (long long)blockIdx.x * 64 + lane;
     const long long r0 = (long long)blockIdx.y * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > p) r1 = p;
     float acc = 0.f;
-    for (long long r = r0; r < r1; ++r) acc += in[r * v + col];
-    out[(long long)blockIdx.y * v + col] = acc;
+    if (col < v)
+        for (long long r = r0 + slice; r < r1; r += 4) acc += in[r * v + col];
+    part[slice][lane] = acc;
+    __syncthreads();
+    if (slice == 0 && col < v)
+        out[(long long)blockIdx.y * v + col] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
-constexpr int kRowsPerBlock = 32;
+// Level 2: out[col] = sum of p <= 32 rows in index order.
+__global__ void __launch_bounds__(kBlock)
+reduce_rows_final_kernel(const float *__restrict__ in, int p, long long v, float *__restrict__ out) {
+    const long long col = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (col >= v) return;
+    float acc = 0.f;
+    for (int r = 0; r < p; ++r) acc += in[(long long)r * v + col];
+    out[col] = acc;
+}
+
+constexpr int kMaxFinalRows = 32;
 
 inline int pow2_ceil(int x) {
     int p = 1;
@@ -115,34 +131,44 @@ inline int pow2_ceil(int x) {
 
 extern "C" {
 
+int64_t rwk_reduce_rows_level1(int64_t p) {
+    if (p <= kMaxFinalRows) return p;
+    return kMaxFinalRows;
+}
+
 int64_t rwk_reduce_rows_workspace(int64_t p, int64_t v) {
-    int64_t total = 0;
-    while (p > kRowsPerBlock) {
-        p = rwk_ceil_div(p, kRowsPerBlock);
-        total += p * v;
-    }
-    return total;
+    return p > kMaxFinalRows ? kMaxFinalRows * v : 0;
+}
+
+int rwk_reduce_rows_to32(const float *in, int64_t p, int64_t v, float *out32, rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(in);
+    RWK_REQUIRE_PTR(out32);
+    if (p <= kMaxFinalRows || v <= 0 || v >= 0x7FFFFFFFll * 64) return RWK_E_SIZE;
+    const int rows_per_block = (int)rwk_ceil_div(p, kMaxFinalRows);
+    // with rows_per_block = ceil(p/32) some trailing row blocks may be empty: they write zeros
+    hipLaunchKernelGGL(reduce_rows_level1_kernel, dim3((unsigned)rwk_ceil_div(v, 64), (unsigned)kMaxFinalRows),
+                       dim3(kBlock), 0, (hipStream_t)stream, in, (long long)p, (long long)v, rows_per_block, out32);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
 }
 
 int rwk_reduce_rows(const float *in, int64_t p, int64_t v, float *out, float *workspace, rwk_stream_t stream) {
     RWK_REQUIRE_PTR(in);
     RWK_REQUIRE_PTR(out);
     if (p <= 0 || v <= 0 || v >= 0x7FFFFFFFll * 64) return RWK_E_SIZE;
-    if (p > kRowsPerBlock) RWK_REQUIRE_PTR(workspace);
     const float *src = in;
-    float *ws = workspace;
-    while (true) {
-        const int64_t blocks_y = rwk_ceil_div(p, kRowsPerBlock);
-        if (blocks_y > 65535) return RWK_E_SIZE;
-        float *dst = blocks_y == 1 ? out : ws;
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)rwk_ceil_div(v, kBlock), (unsigned)blocks_y),
-                           dim3(kBlock), 0, (hipStream_t)stream, src, (long long)p, (long long)v, kRowsPerBlock, dst);
-        RWK_LAUNCH_CHECK();
-        if (blocks_y == 1) return RWK_OK;
-        src = dst;
-        ws += blocks_y * v;
-        p = blocks_y;
+    int rows = (int)p;
+    if (p > kMaxFinalRows) {
+        RWK_REQUIRE_PTR(workspace);
+        const int rc = rwk_reduce_rows_to32(in, p, v, workspace, stream);
+        if (rc != RWK_OK) return rc;
+        src = workspace;
+        rows = kMaxFinalRows;
     }
+    hipLaunchKernelGGL(reduce_rows_final_kernel, dim3((unsigned)rwk_ceil_div(v, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, src, rows, (long long)v, out);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
 }
 
 int rwk_project_forward(const float *features, const float *weight, const float *bias, int64_t n, int64_t f,

@@ -137,11 +137,17 @@ class _RWKernelLayer(torch.autograd.Function):
                        "rwk_fused_backward")
             for i in range(steps - 1, 0, -1):
                 st.spmm(dx[i], dx[i - 1], transpose=True, accumulate=True)      # dX[i-1] += A^T dX[i]
-            dz = _reduce_rows(lib, dz_partials, stream)
+            # dZ partials: first level here (to at most 32 rows), the rest inside rwk_hidden_backward
+            dz, dz_rows = dz_partials, n_part
+            if n_part > 32:
+                dz_rows = lib.rwk_reduce_rows_level1(n_part)
+                dz = torch.empty((dz_rows, dz_partials.shape[1]), dtype=torch.float32, device=dev)
+                _lib.check(lib.rwk_reduce_rows_to32(dz_partials.data_ptr(), n_part, dz_partials.shape[1],
+                                                    dz.data_ptr(), stream), "rwk_reduce_rows_to32")
             d_adj = torch.empty_like(adj_hidden_c)
             d_feat = torch.empty((n_hidden, s, d), dtype=torch.float32, device=dev)
             _lib.check(lib.rwk_hidden_backward(_lib.ptr(adj_hidden_c), ah.data_ptr(), z.data_ptr(),
-                                               dz.data_ptr(), 1, n_hidden, s, d, steps,
+                                               dz.data_ptr(), dz_rows, n_hidden, s, d, steps,
                                                _lib.ptr(d_adj), d_feat.data_ptr(), stream),
                        "rwk_hidden_backward")
             x0 = xs[0]

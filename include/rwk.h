@@ -178,12 +178,27 @@ int rwk_project_backward(const float *dx0, const float *x0, const float *feature
                          const float *weight, int64_t n, int64_t f, int64_t d, float *partials,
                          float *d_features, rwk_stream_t stream);
 
-/* out[v] = sum_p in[p, v], rows added in a fixed tree order (32 consecutive rows per level),
- * so the result is bitwise reproducible.  workspace: rwk_reduce_rows_workspace(p, v) floats
- * (0 when p <= 32). */
+/* out[v] = sum_p in[p, v], rows added in a fixed order (p > 32: 32 row blocks of ceil(p/32) rows,
+ * each summed by 4 interleaved slices, then the 32 block sums in index order), so the result is
+ * bitwise reproducible.  workspace: rwk_reduce_rows_workspace(p, v) floats (0 when p <= 32). */
 int64_t rwk_reduce_rows_workspace(int64_t p, int64_t v);
 int rwk_reduce_rows(const float *in, int64_t p, int64_t v, float *out, float *workspace,
                     rwk_stream_t stream);
+/* First level only: p > 32 rows -> out32 (32, v).  rwk_reduce_rows_level1(p) = rows left
+ * after it (p itself when p <= 32, else 32); rwk_hidden_backward adds up to 32 rows itself. */
+int64_t rwk_reduce_rows_level1(int64_t p);
+int rwk_reduce_rows_to32(const float *in, int64_t p, int64_t v, float *out32, rwk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Adam over one flat parameter buffer (torch.optim.Adam semantics, rwgnn2/main.py:79,87):
+ * one launch per step.  lr: device float[1].  step_counters: rwk_adam_n_counters(n) device
+ * int64, zero before the first step (the step count lives on the device, so a captured
+ * graph replays correctly).
+ * ------------------------------------------------------------------------------------- */
+int64_t rwk_adam_n_counters(int64_t n);
+int rwk_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                  const float *lr, float beta1, float beta2, float eps, float weight_decay,
+                  int64_t *step_counters, rwk_stream_t stream);
 
 /* Test hook: writes the keep-mask exactly as the fused kernels draw it, one byte per element,
  * shape (L, H, S, N), for the {seed, offset} in rng. */

@@ -1,0 +1,127 @@
+"""GPU tests of the helper kernels around the layer: deterministic row reduction, fused input projection,
+flat Adam, HIP-graph replay of a whole training step."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _golden import GoldenCase, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("p,v", [(1, 7), (32, 640), (33, 5), (1203, 640), (5000, 70)])
+def test_reduce_rows(p, v, dev):
+    from gnn_amd import _lib
+    lib = _lib.load()
+    x = torch.randn(p, v, device=dev)
+    out = torch.empty(v, device=dev)
+    ws = torch.empty(max(1, lib.rwk_reduce_rows_workspace(p, v)), device=dev)
+    stream = _lib.current_stream(dev)
+    _lib.check(lib.rwk_reduce_rows(x.data_ptr(), p, v, out.data_ptr(), ws.data_ptr(), stream), "reduce")
+    want = x.double().sum(0).cpu().numpy()
+    assert rel_err(out.cpu().numpy(), want) < 1e-5
+    out2 = torch.empty(v, device=dev)
+    _lib.check(lib.rwk_reduce_rows(x.data_ptr(), p, v, out2.data_ptr(), ws.data_ptr(), stream), "reduce")
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("n,f,d", [(1000, 1, 4), (777, 3, 6), (64, 8, 16), (5000, 2, 64)])
+def test_projection_forward_backward(n, f, d, dev):
+    from gnn_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(n + f + d)
+    feat = torch.randn(n, f, generator=g).to(dev)
+    w = torch.randn(d, f, generator=g).to(dev)
+    b = torch.randn(d, generator=g).to(dev)
+    dx0 = torch.randn(n, d, generator=g).to(dev)
+    stream = _lib.current_stream(dev)
+    x0 = torch.empty(n, d, device=dev)
+    _lib.check(lib.rwk_project_forward(feat.data_ptr(), w.data_ptr(), b.data_ptr(), n, f, d, x0.data_ptr(), stream),
+               "project_forward")
+    fd, wd, bd = feat.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = torch.sigmoid(fd @ wd.t() + bd)
+    assert rel_err(x0.cpu().numpy(), ref.detach().cpu().numpy()) < 1e-6
+    ref.backward(dx0.double())
+    blocks = lib.rwk_project_backward_blocks(n, d)
+    partials = torch.empty(blocks, d * f + d, device=dev)
+    d_feat = torch.empty(n, f, device=dev)
+    _lib.check(lib.rwk_project_backward(dx0.data_ptr(), x0.data_ptr(), feat.data_ptr(), w.data_ptr(), n, f, d,
+                                        partials.data_ptr(), d_feat.data_ptr(), stream), "project_backward")
+    tot = partials.double().sum(0).cpu().numpy()
+    assert rel_err(tot[:d * f].reshape(d, f), wd.grad.cpu().numpy()) < 1e-5
+    assert rel_err(tot[d * f:], bd.grad.cpu().numpy()) < 1e-5
+    assert rel_err(d_feat.cpu().numpy(), fd.grad.cpu().numpy()) < 1e-5
+
+
+def test_flat_adam_matches_torch_adam(dev):
+    from gnn_amd.dp import FlatGradBucket
+    from gnn_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    net_a = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3)).to(dev)
+    net_b = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3)).to(dev)
+    net_b.load_state_dict(net_a.state_dict())
+    opt_a = torch.optim.Adam(net_a.parameters(), lr=1e-2, weight_decay=1e-3)
+    bucket = FlatGradBucket(net_b)
+    opt_b = FlatAdam(net_b, bucket, lr=1e-2, weight_decay=1e-3)
+    x = torch.randn(32, 7, device=dev)
+    y = torch.randn(32, 3, device=dev)
+    for it in range(25):
+        opt_a.zero_grad()
+        F.mse_loss(net_a(x), y).backward()
+        opt_a.step()
+        opt_b.zero_grad()
+        F.mse_loss(net_b(x), y).backward()
+        opt_b.step()
+    for pa, pb in zip(net_a.parameters(), net_b.parameters()):
+        assert rel_err(pb.detach().cpu().numpy(), pa.detach().cpu().numpy()) < 1e-5
+    assert int(opt_b.step_counters[0].item()) == 25
+
+
+def _trainer(c, hp, dev, seed=99):
+    import bench
+    from gnn_amd import RW_NN
+    torch.manual_seed(1)
+    m = RW_NN(hp["input_dim"], hp["max_step"], hp["hidden_graphs"], hp["size_hidden_graphs"], hp["hidden_dim"],
+              hp["penultimate_dim"], bool(hp["normalize"]), hp["n_classes"], hp["dropout"], dev).to(dev)
+    m.load_state_dict(c.torch_state())
+    m.train()
+    m.seed_dropout(seed)
+    return bench.Trainer(m, c.torch_inputs(dev), 1)
+
+
+def test_graph_replay_trains_like_eager(dev):
+    """Without dropout the captured step and the eager step follow the same trajectory."""
+    c = GoldenCase("mutag_b0")
+    hp = dict(c.hp, dropout=0.0)
+    eager, graph = _trainer(c, hp, dev), _trainer(c, hp, dev)
+    graph.capture()                      # runs 3 eager warm-up steps, then captures
+    for _ in range(3):
+        eager.step_eager()
+    for _ in range(5):
+        eager.step_eager()
+        graph.step_graph()
+        assert abs(float(eager.loss) - float(graph.loss)) < 1e-4 * abs(float(eager.loss))
+    for pe, pg in zip(eager.model.parameters(), graph.model.parameters()):
+        assert rel_err(pg.detach().cpu().numpy(), pe.detach().cpu().numpy()) < 1e-3
+
+
+def test_graph_replay_draws_fresh_dropout_masks(dev):
+    """The dropout offset lives on the device: every replay of the captured step advances it."""
+    c = GoldenCase("mutag_b0")
+    graph = _trainer(c, dict(c.hp, dropout=0.2), dev)
+    graph.capture()
+    offsets, losses = [], []
+    for _ in range(5):
+        graph.step_graph()
+        offsets.append(int(graph.model._rng_state[1].item()))
+        losses.append(float(graph.loss))
+    assert offsets == list(range(offsets[0], offsets[0] + 5))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0] + 0.2
