@@ -16,6 +16,9 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int DP = 4;
+// Waves per SIMD the backward kernel is compiled for: L*S*4 dZ accumulators + L*S*4 rows of Z must fit.
+// 4 (<= 128 VGPRs, four 256-thread workgroups per CU) up to L*S = 10, then 2, then 1.
+constexpr int bwd_waves_per_simd(int ls) { return ls <= 10 ? 4 : (ls <= 24 ? 2 : 1); }
 
 struct DropCfg {
     uint32_t t0, t1, seed_lo, key_hi, off_lo;
@@ -103,14 +106,19 @@ struct Tile {
     int node[kBlock];
 };
 
+// Slots past the end of a stream carry zero rows (so they contribute nothing), node = -1, and the graph id
+// of the stream's last position (so they never trigger a flush): the loops below need no validity branch.
 template <int LT>
 __device__ inline void load_tile(Tile<LT> &tile, const float *__restrict__ x, const int *__restrict__ gid,
-                                 const int *__restrict__ perm, int p, bool valid, int d, size_t step_stride) {
+                                 const int *__restrict__ perm, int p, int end, bool has_stream, int d,
+                                 size_t step_stride) {
     const int t = threadIdx.x;
+    const bool valid = has_stream && p < end;
     int node = -1, g = -1;
-    if (valid) {
-        node = perm ? perm[p] : p;
-        g = gid[p];
+    if (has_stream) {
+        const int pc = valid ? p : end - 1;
+        g = gid[pc];
+        if (valid) node = perm ? perm[p] : p;
     }
     tile.node[t] = node;
     tile.gid[t] = g;
@@ -122,12 +130,14 @@ __device__ inline void load_tile(Tile<LT> &tile, const float *__restrict__ x, co
     }
 }
 
-template <int LT, int ST, bool DROP>
+// HPT: lanes per stream as a compile-time constant (0 = use the run-time value hp_arg)
+template <int LT, int ST, bool DROP, int HPT>
 __global__ void __launch_bounds__(kBlock)
 forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const int *__restrict__ gid,
-               const int *__restrict__ perm, int n, int d, int h, int stream_len, int hp, uint32_t t0, uint32_t t1,
-               const unsigned long long *__restrict__ rng, float *__restrict__ k_partials) {
+               const int *__restrict__ perm, int n, int d, int h, int stream_len, int hp_arg, uint32_t t0,
+               uint32_t t1, const unsigned long long *__restrict__ rng, float *__restrict__ k_partials) {
     constexpr int NC = (LT * ST + 14) / 15;
+    const int hp = HPT ? HPT : hp_arg;
     __shared__ Tile<LT> tile;
     const int tid = threadIdx.x;
     const int lane_h = tid % hp;
@@ -152,12 +162,12 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
 
     for (int base = 0; base < stream_len; base += hp) {
         __syncthreads();
-        load_tile<LT>(tile, x, gid, perm, start + base + lane_h, has_stream && start + base + lane_h < end, d,
-                      step_stride);
+        load_tile<LT>(tile, x, gid, perm, start + base + lane_h, end, has_stream, d, step_stride);
         __syncthreads();
-        for (int j = 0; j < hp; ++j) {
+        const int jmax = stream_len - base < hp ? stream_len - base : hp;
+#pragma unroll 2
+        for (int j = 0; j < jmax; ++j) {
             const int node = tile.node[group0 + j];
-            if (node < 0) break;                          // end of this stream (uniform over the stream's lanes)
             const int g = tile.gid[group0 + j];
             if (g != g_cur) {
                 if (g_cur >= 0 && lane_h < h) {
@@ -202,16 +212,17 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
     }
 }
 
-template <int LT, int ST, bool DROP>
-__global__ void __launch_bounds__(kBlock)
+template <int LT, int ST, bool DROP, int HPT>
+__global__ void __launch_bounds__(kBlock, bwd_waves_per_simd(LT * ST))
 backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const int *__restrict__ gid,
                 const int *__restrict__ perm, const float *__restrict__ d_k, const float *__restrict__ counts_f32,
-                int n, int d, int h, int stream_len, int hp, float scale, int normalize, uint32_t t0, uint32_t t1,
-                const unsigned long long *__restrict__ rng, float *__restrict__ dx,
+                int n, int d, int h, int stream_len, int hp_arg, float scale, int normalize, uint32_t t0,
+                uint32_t t1, const unsigned long long *__restrict__ rng, float *__restrict__ dx,
                 float *__restrict__ dz_partials) {
     constexpr int NC = (LT * ST + 14) / 15;
+    const int hp = HPT ? HPT : hp_arg;
     constexpr int V = LT * ST * DP;               // gradient values per lane
-    constexpr int CH = V < 32 ? V : 32;           // values staged per LDS round of the final reduction
+    constexpr int CH = V < 16 ? V : 16;           // values staged per LDS round of the final reduction
     __shared__ Tile<LT> tile;
     __shared__ float red[CH][kBlock];
 
@@ -242,9 +253,8 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
 
     for (int base = 0; base < stream_len; base += hp) {
         const int my_p = start + base + lane_h;          // the slot this lane loads and later stores
-        const bool my_valid = has_stream && my_p < end;
         __syncthreads();
-        load_tile<LT>(tile, x, gid, perm, my_p, my_valid, d, step_stride);
+        load_tile<LT>(tile, x, gid, perm, my_p, end, has_stream, d, step_stride);
         __syncthreads();
         const int my_node = tile.node[tid];
         float mine[LT][DP];                               // dX rows of this lane's own slot
@@ -253,9 +263,11 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
 #pragma unroll
             for (int k = 0; k < DP; ++k) mine[i][k] = 0.f;
         // every lane of the wavefront runs all hp iterations: the DPP butterfly needs them all
-        for (int j = 0; j < hp; ++j) {
+        const int jmax = stream_len - base < hp ? stream_len - base : hp;
+#pragma unroll 2
+        for (int j = 0; j < jmax; ++j) {
             const int node = tile.node[group0 + j];
-            const bool valid = node >= 0;
+            const int g = tile.gid[group0 + j];
             float xr[LT][DP], dxr[LT][DP];
 #pragma unroll
             for (int i = 0; i < LT; ++i) {
@@ -264,16 +276,17 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
 #pragma unroll
                 for (int k = 0; k < DP; ++k) dxr[i][k] = 0.f;
             }
-            if (valid) {
-                const int g = tile.gid[group0 + j];
-                if (g != g_cur) {
-                    g_cur = g;
-                    float f = scale;
-                    if (normalize) f /= counts_f32[g];
+            if (g != g_cur) {                             // first node of a graph: fetch its dK row
+                g_cur = g;
+                float f = scale;
+                if (normalize) f /= counts_f32[g];
 #pragma unroll
-                    for (int i = 0; i < LT; ++i)
-                        dp_cur[i] = own_h ? d_k[(size_t)g * lh + i * h + lane_h] * f : 0.f;
-                }
+                for (int i = 0; i < LT; ++i)
+                    dp_cur[i] = own_h ? d_k[(size_t)g * lh + i * h + lane_h] * f : 0.f;
+            }
+            // no validity branch: a slot past the end of the stream has x = 0, so zx = t = 0 and every
+            // product below is zero
+            {
                 Keep<NC> keep;
                 if (DROP) keep.draw(cfg, (uint32_t)node, (uint32_t)lane_h);
 #pragma unroll
@@ -362,12 +375,12 @@ int launch_fwd(const Args &a) {
     const int hp = pow2_ceil(a.h);
     const int n_streams = (int)rwk_ceil_div(a.n, a.stream_len);
     const dim3 grid((unsigned)rwk_ceil_div(n_streams, kBlock / hp));
-    if (a.drop)
-        hipLaunchKernelGGL((forward_kernel<LT, ST, true>), grid, dim3(kBlock), 0, a.stream, a.x, a.z, a.gid, a.perm,
-                           a.n, a.d, a.h, a.stream_len, hp, a.t0, a.t1, a.rng, a.k_partials);
-    else
-        hipLaunchKernelGGL((forward_kernel<LT, ST, false>), grid, dim3(kBlock), 0, a.stream, a.x, a.z, a.gid, a.perm,
-                           a.n, a.d, a.h, a.stream_len, hp, a.t0, a.t1, a.rng, a.k_partials);
+#define RWK_FWD(DROPV, HPV)                                                                                       \
+    hipLaunchKernelGGL((forward_kernel<LT, ST, DROPV, HPV>), grid, dim3(kBlock), 0, a.stream, a.x, a.z, a.gid, a.perm, \
+                       a.n, a.d, a.h, a.stream_len, hp, a.t0, a.t1, a.rng, a.k_partials)
+    if (hp == 16) { if (a.drop) RWK_FWD(true, 16); else RWK_FWD(false, 16); }
+    else { if (a.drop) RWK_FWD(true, 0); else RWK_FWD(false, 0); }
+#undef RWK_FWD
     RWK_LAUNCH_CHECK();
     return RWK_OK;
 }
@@ -376,14 +389,13 @@ template <int LT, int ST>
 int launch_bwd(const Args &a) {
     const int hp = pow2_ceil(a.h);
     const dim3 grid((unsigned)backward_blocks(a.n, a.stream_len, a.h));
-    if (a.drop)
-        hipLaunchKernelGGL((backward_kernel<LT, ST, true>), grid, dim3(kBlock), 0, a.stream, a.x, a.z, a.gid, a.perm,
-                           a.d_k, a.counts_f32, a.n, a.d, a.h, a.stream_len, hp, a.scale, a.normalize, a.t0, a.t1,
-                           a.rng, a.dx, a.dz_partials);
-    else
-        hipLaunchKernelGGL((backward_kernel<LT, ST, false>), grid, dim3(kBlock), 0, a.stream, a.x, a.z, a.gid, a.perm,
-                           a.d_k, a.counts_f32, a.n, a.d, a.h, a.stream_len, hp, a.scale, a.normalize, a.t0, a.t1,
-                           a.rng, a.dx, a.dz_partials);
+#define RWK_BWD(DROPV, HPV)                                                                                        \
+    hipLaunchKernelGGL((backward_kernel<LT, ST, DROPV, HPV>), grid, dim3(kBlock), 0, a.stream, a.x, a.z, a.gid, a.perm, \
+                       a.d_k, a.counts_f32, a.n, a.d, a.h, a.stream_len, hp, a.scale, a.normalize, a.t0, a.t1, a.rng, \
+                       a.dx, a.dz_partials)
+    if (hp == 16) { if (a.drop) RWK_BWD(true, 16); else RWK_BWD(false, 16); }
+    else { if (a.drop) RWK_BWD(true, 0); else RWK_BWD(false, 0); }
+#undef RWK_BWD
     RWK_LAUNCH_CHECK();
     return RWK_OK;
 }

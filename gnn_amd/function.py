@@ -36,11 +36,13 @@ def _pow2_ceil(v: int) -> int:
 
 def choose_stream_len(n_nodes: int, n_hidden: int) -> int:
     """Sorted positions walked sequentially by one lane group of the fused kernels."""
+    # Workgroups of 256 threads hold 256/hp streams; 256 CUs x 4 resident workgroups = 1024 slots.
+    # Aim at a whole number m of full rounds of 1024 workgroups with about 20 positions per stream:
+    # a last round that is mostly empty costs as much as a full one.
     hp = _pow2_ceil(n_hidden)
-    want = -(-n_nodes * hp // _TARGET_LANES)
-    want = max(16, min(512, want))
-    # the kernels stage positions in tiles of hp: keep the stream a whole number of tiles
-    return hp * max(1, round(want / hp))
+    per_round = (256 // hp) * 1024
+    m = max(1, round(n_nodes / (per_round * 20)))
+    return max(8, -(-n_nodes // (per_round * m)))
 
 
 def _reduce_rows(lib, partials2d, stream):

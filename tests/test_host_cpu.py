@@ -101,7 +101,7 @@ def test_spmm_schedule_rule():
 
 def test_stream_length_rule():
     from gnn_amd.function import choose_stream_len
-    assert choose_stream_len(1168, 16) == 16
-    assert choose_stream_len(307000, 16) == 16
-    assert choose_stream_len(50_000_000, 16) == 512
-    assert choose_stream_len(1000, 64) == 64
+    assert choose_stream_len(1168, 16) == 8
+    assert choose_stream_len(307842, 16) == 19          # 1013 workgroups: one round of the 1024 slots
+    assert choose_stream_len(50_000_000, 16) == 20
+    assert choose_stream_len(103008, 64) == 26
