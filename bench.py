@@ -124,12 +124,14 @@ def time_kernels(model, batch_t, hp, iters=50):
     z = torch.rand((steps, h, s, d), device=dev)
     dk = torch.randn((g, steps * h), device=dev)
     rng = torch.tensor([12345, 7], dtype=torch.int64, device=dev)
-    stream_len = choose_stream_len(n, h)
+    stream_len = choose_stream_len(n, h, lib.rwk_fused_path(d, h, s, steps))
     n_streams = lib.rwk_fused_n_streams(n, stream_len)
     k_part = torch.empty(lib.rwk_fused_k_partials_size(n, stream_len, g, h, steps), device=dev)
     n_part = lib.rwk_fused_dz_partials_count(n, stream_len, d, h, s, steps)
     dz_part = torch.empty((n_part, steps, h, s, d), device=dev)
     dx = torch.empty_like(xs)
+    ws_n = lib.rwk_fused_backward_workspace(n, d, h, s, steps)
+    ws = torch.empty(ws_n, device=dev) if ws_n else None
     y = torch.empty((n, d), device=dev)
 
     def run_spmm():
@@ -142,7 +144,8 @@ def time_kernels(model, batch_t, hp, iters=50):
     def run_bwd():
         _lib.check(lib.rwk_fused_backward(xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm),
                                           dk.data_ptr(), st.counts_f32.data_ptr(), n, d, h, s, steps, stream_len, p,
-                                          0, rng.data_ptr(), dx.data_ptr(), dz_part.data_ptr(), stream), "bwd")
+                                          0, rng.data_ptr(), dx.data_ptr(), dz_part.data_ptr(), _lib.ptr(ws), stream),
+                   "bwd")
 
     lh = steps * h
     bytes_ = {

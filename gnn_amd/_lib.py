@@ -34,7 +34,9 @@ SIGNATURES = {
     "rwk_fused_forward": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_float, _P, _P, _P]),
     "rwk_fused_reduce": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, c_float, c_int, _P, _P]),
     "rwk_fused_backward": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_float, c_int,
-                                   _P, _P, _P, _P]),
+                                   _P, _P, _P, _P, _P]),
+    "rwk_fused_backward_workspace": (_I64, [_I64, _I64, _I64, _I64, _I64]),
+    "rwk_fused_path": (c_int, [_I64, _I64, _I64, _I64]),
     "rwk_project_forward": (c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
     "rwk_project_backward_blocks": (_I64, [_I64, _I64]),
     "rwk_project_backward": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P]),

@@ -18,6 +18,7 @@
 // HBM bytes per call (roofline figure): forward  L*N*D*4 + N*4 (+ N*4 with perm) + slots*L*H*4;
 //                                        backward 2*L*N*D*4 + N*4 + G*L*H*4 + partials.
 #include "rwk_common.h"
+#include "rwk_fused_mfma.h"
 #include "rwk_fused_reg.h"
 
 namespace {
@@ -527,8 +528,22 @@ int64_t rwk_fused_dz_partials_count(int64_t n, int64_t stream_len, int64_t d, in
     FusedPlan plan;
     if (!sizes_ok(n, d, h, s, max_step, stream_len)) return 0;
     if (rwk_reg::supported(d, h, s, max_step)) return rwk_reg::backward_blocks(n, stream_len, h);
+    if (rwk_mfma::supported(d, h, s, max_step)) return rwk_mfma::backward_blocks(n, stream_len);
     if (!plan_for(n, d, h, s, max_step, stream_len, true, &plan)) return 0;
     return plan.n_blocks;
+}
+
+int64_t rwk_fused_backward_workspace(int64_t n, int64_t d, int64_t h, int64_t s, int64_t max_step) {
+    if (n <= 0 || d <= 0 || h <= 0 || s <= 0 || max_step <= 0) return 0;
+    if (rwk_reg::supported(d, h, s, max_step)) return 0;
+    if (rwk_mfma::supported(d, h, s, max_step)) return rwk_mfma::dx_partials_size(n, d, h, max_step);
+    return 0;
+}
+
+int rwk_fused_path(int64_t d, int64_t h, int64_t s, int64_t max_step) {
+    if (rwk_reg::supported(d, h, s, max_step)) return 1;
+    if (rwk_mfma::supported(d, h, s, max_step)) return 2;
+    return 0;
 }
 
 int rwk_fused_forward(const float *x, const float *z, const int32_t *gid, const int32_t *perm, int64_t n,
@@ -548,6 +563,15 @@ int rwk_fused_forward(const float *x, const float *z, const int32_t *gid, const 
         r.stream = (hipStream_t)stream; r.k_partials = k_partials;
         rwk_drop_thresholds(drop_p, &r.t0, &r.t1);
         return rwk_reg::forward(r);
+    }
+    if (rwk_mfma::supported(d, h, s, max_step)) {
+        rwk_mfma::Args r{};
+        r.x = x; r.z = z; r.gid = gid; r.perm = perm;
+        r.n = (int)n; r.d = (int)d; r.h = (int)h; r.s = (int)s; r.max_step = (int)max_step;
+        r.stream_len = (int)stream_len; r.drop = drop; r.rng = (const unsigned long long *)rng;
+        r.stream = (hipStream_t)stream; r.k_partials = k_partials;
+        rwk_drop_thresholds(drop_p, &r.t0, &r.t1);
+        return rwk_mfma::forward(r);
     }
     FusedPlan plan;
     if (!plan_for(n, d, h, s, max_step, stream_len, false, &plan)) return RWK_E_UNSUPPORTED;
@@ -585,7 +609,7 @@ int rwk_fused_reduce(const float *k_partials, const int32_t *seg_ptr, const floa
 int rwk_fused_backward(const float *x, const float *z, const int32_t *gid, const int32_t *perm, const float *d_k,
                        const float *counts_f32, int64_t n, int64_t d, int64_t h, int64_t s, int64_t max_step,
                        int64_t stream_len, float drop_p, int normalize, const uint64_t *rng, float *dx,
-                       float *dz_partials, rwk_stream_t stream) {
+                       float *dz_partials, float *workspace, rwk_stream_t stream) {
     RWK_REQUIRE_PTR(x);
     RWK_REQUIRE_PTR(z);
     RWK_REQUIRE_PTR(gid);
@@ -605,6 +629,18 @@ int rwk_fused_backward(const float *x, const float *z, const int32_t *gid, const
         r.dx = dx; r.dz_partials = dz_partials;
         rwk_drop_thresholds(drop_p, &r.t0, &r.t1);
         return rwk_reg::backward(r);
+    }
+    if (rwk_mfma::supported(d, h, s, max_step)) {
+        rwk_mfma::Args r{};
+        r.x = x; r.z = z; r.gid = gid; r.perm = perm;
+        r.n = (int)n; r.d = (int)d; r.h = (int)h; r.s = (int)s; r.max_step = (int)max_step;
+        r.stream_len = (int)stream_len; r.drop = drop; r.rng = (const unsigned long long *)rng;
+        r.stream = (hipStream_t)stream; r.d_k = d_k; r.counts_f32 = counts_f32;
+        r.scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f; r.normalize = normalize;
+        r.dx = dx; r.dz_partials = dz_partials; r.dx_partials = workspace;
+        if (rwk_mfma::dx_partials_size(n, d, h, max_step) > 0 && workspace == nullptr) return RWK_E_NULL;
+        rwk_drop_thresholds(drop_p, &r.t0, &r.t1);
+        return rwk_mfma::backward(r);
     }
     FusedPlan plan;
     if (!plan_for(n, d, h, s, max_step, stream_len, true, &plan)) return RWK_E_UNSUPPORTED;

@@ -1,0 +1,538 @@
+// Fused random-walk kernels on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, bit-for-bit an
+// fmaf chain) for hidden_dim > 4.
+//
+// Tile algebra.  One MFMA computes D(16x16) += A(16x4) B(4x16); lane l supplies A[l&15][l>>4] and
+// B[l>>4][l&15] and receives D[4*(l>>4)+r][l&15], r = 0..3.  With q = l>>4 and c = l&15:
+//
+//   T = Z X^T  (16 hidden graphs x 16 nodes):  A = Z_i[h = c][d],  B = X_i[node = c][d]; the four d's of one
+//       16-byte chunk (d = 16*tc + 4*q + e, e = 0..3) are the k-slots of four consecutive MFMAs, so each
+//       operand is one 16-byte load per four MFMAs.  The lane ends up with T[h = 4q+r][node = c].
+//   dX = G^T Z (16 nodes x 16 d's): the accumulator registers of G are used directly as the A operand: in
+//       the MFMA for register r, k-slot q stands for hidden graph 4q+r, so B = Z_i[h = 4q+r][16*tc + c].
+//   dZ = G X   (16 hidden graphs x 16 d's): needs G transposed (node on the k index): one 16x16 transpose
+//       through LDS, then A = G^T register r (k-slot q = node 4q+r), B = X_i[node = 4q+r][16*tc + c].
+//
+// Rows of a tile are 16 hidden graphs at a fixed hidden node s, so the sum over s is a sum of accumulator
+// tiles in registers.  A workgroup owns one block of 16 hidden graphs (blockIdx.y) and keeps their Z rows of
+// all steps in LDS.  Columns are 16 independent streams of consecutive sorted positions, as in the
+// vector-ALU kernels: partial sums go to slot (stream + graph) of k_partials, no atomics anywhere.
+#include "rwk_fused_mfma.h"
+
+namespace rwk_mfma {
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kFwdBlock = 512;     // 8 wavefronts, each with its own 16 streams
+constexpr int kBwdBlock = 256;     // 4 wavefronts sharing 16 streams, splitting the hidden nodes s
+constexpr int kBwdWaves = 4;
+constexpr int kSwMax = 3;          // hidden nodes per wavefront in backward: S <= 12
+constexpr size_t kLdsBudget = 150 * 1024;
+
+struct DropCfg {
+    uint32_t t0, t1, seed_lo, key_hi, off_lo;
+};
+
+__device__ inline DropCfg load_cfg(const unsigned long long *rng, uint32_t t0, uint32_t t1) {
+    const unsigned long long seed = rng[0], off = rng[1];
+    return DropCfg{t0, t1, (uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(off >> 32), (uint32_t)off};
+}
+
+// keep bits of the (node, hidden graph) stream: bit e <-> sample e = s*L + i  (n_calls*15 <= 45 samples)
+__device__ inline unsigned long long keep_bits(const DropCfg &c, uint32_t node, uint32_t hq, int n_calls) {
+    unsigned long long bits = 0;
+#pragma unroll
+    for (int call = 0; call < 3; ++call) {
+        if (call < n_calls) {
+            const RwkPhilox4 r = rwk_philox4x32_10(node, hq, (uint32_t)call, c.off_lo, c.seed_lo, c.key_hi);
+            const uint32_t thr = c.t0 + ((r.w >> 24) < c.t1 ? 1u : 0u);
+            const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+            uint32_t m = 0;
+#pragma unroll
+            for (int j = 0; j < 15; ++j) m |= (((w[j >> 2] >> (8 * (j & 3))) & 0xFFu) < thr ? 1u : 0u) << j;
+            bits |= (unsigned long long)m << (15 * call);
+        }
+    }
+    return bits;
+}
+
+// four floats of a row starting at column off (zero beyond d); every load is unconditional
+__device__ inline float4 load4(const float *__restrict__ row, int d, int off, bool aligned) {
+    if (aligned && off + 3 < d) return *reinterpret_cast<const float4 *>(row + off);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = off + e;
+        const float t = row[k < d ? k : d - 1];
+        v[e] = k < d ? t : 0.f;
+    }
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// Z rows of hidden graphs [16*hb, 16*hb+16), all steps and hidden nodes, into LDS: [i][s][16][ZS]
+template <int LT, int NT>
+__device__ inline void stage_z(const float *__restrict__ z, float *zs, int h, int s, int d, int hb, int block) {
+    constexpr int DPAD = 16 * NT, ZS = DPAD + 4;
+    const int total = LT * s * 16 * DPAD;
+    for (int idx = threadIdx.x; idx < total; idx += block) {
+        const int k = idx % DPAD;
+        int r = idx / DPAD;
+        const int hl = r % 16; r /= 16;
+        const int ss = r % s;
+        const int i = r / s;
+        const int hq = 16 * hb + hl;
+        const float v = z[(((size_t)i * h + (hq < h ? hq : h - 1)) * s + ss) * d + (k < d ? k : d - 1)];
+        zs[((i * s + ss) * 16 + hl) * ZS + k] = (hq < h && k < d) ? v : 0.f;
+    }
+}
+
+#define RWK_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// acc(16 h x 16 nodes) = Z_i[s] X_i^T for this lane's fragments: zrow points at Z_i[s][h = lane&15][0]
+template <int NT>
+__device__ inline f32x4 tile_zx(const float *zrow, int q, const float4 (&xv)[NT]) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tc = 0; tc < NT; ++tc) {
+        const float4 a = *reinterpret_cast<const float4 *>(zrow + 16 * tc + 4 * q);
+        acc = RWK_MFMA(a.x, xv[tc].x, acc);
+        acc = RWK_MFMA(a.y, xv[tc].y, acc);
+        acc = RWK_MFMA(a.z, xv[tc].z, acc);
+        acc = RWK_MFMA(a.w, xv[tc].w, acc);
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int LT, int NT, bool DROP>
+__global__ void __launch_bounds__(kFwdBlock)
+forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const int *__restrict__ gid,
+               const int *__restrict__ perm, int n, int d, int h, int s, int stream_len, int n_calls, uint32_t t0,
+               uint32_t t1, const unsigned long long *__restrict__ rng, float *__restrict__ k_partials) {
+    constexpr int DPAD = 16 * NT, ZS = DPAD + 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *zs = lds;
+    const int hb = blockIdx.y;
+    stage_z<LT, NT>(z, zs, h, s, d, hb, kFwdBlock);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, col = lane & 15;
+    const int c = (blockIdx.x * (kFwdBlock / 64) + wave) * 16 + col;       // this column's stream
+    const long long start_ll = (long long)c * stream_len;
+    const bool has_stream = start_ll < n;
+    const int start = has_stream ? (int)start_ll : 0;
+    const int end = has_stream ? (int)(start_ll + stream_len < n ? start_ll + stream_len : n) : 0;
+    const bool aligned = (d & 3) == 0;
+    DropCfg cfg;
+    if (DROP) cfg = load_cfg(rng, t0, t1);
+    const int lh = LT * h;
+    const size_t step_stride = (size_t)n * d;
+    const int hq0 = 16 * hb + 4 * q;                                       // hidden graph of register 0
+
+    float acc[LT][4];
+#pragma unroll
+    for (int i = 0; i < LT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+    int g_cur = -1;
+
+    for (int t = 0; t < stream_len; ++t) {        // uniform: the MFMAs need every lane of the wavefront
+        const int p = start + t;
+        const bool valid = has_stream && p < end;
+        int node = 0, g = g_cur;
+        if (valid) {
+            node = perm ? perm[p] : p;
+            g = gid[p];
+        }
+        if (g != g_cur) {
+            if (g_cur >= 0) {
+#pragma unroll
+                for (int i = 0; i < LT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (hq0 + r < h) k_partials[(size_t)(c + g_cur) * lh + i * h + hq0 + r] = acc[i][r];
+            }
+#pragma unroll
+            for (int i = 0; i < LT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+            g_cur = g;
+        }
+        float4 xv[LT][NT];
+#pragma unroll
+        for (int i = 0; i < LT; ++i)
+#pragma unroll
+            for (int tc = 0; tc < NT; ++tc) {
+                const float4 v = load4(x + i * step_stride + (size_t)node * d, d, 16 * tc + 4 * q, aligned);
+                xv[i][tc] = valid ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        unsigned long long kb[4] = {0, 0, 0, 0};
+        if (DROP) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) kb[r] = keep_bits(cfg, (uint32_t)node, (uint32_t)(hq0 + r), n_calls);
+        }
+        float node_acc[LT][4];
+#pragma unroll
+        for (int i = 0; i < LT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) node_acc[i][r] = 0.f;
+        for (int ss = 0; ss < s; ++ss) {
+            f32x4 tt[LT];
+#pragma unroll
+            for (int i = 0; i < LT; ++i) tt[i] = tile_zx<NT>(zs + ((i * s + ss) * 16 + col) * ZS, q, xv[i]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                uint32_t kk = 0;
+                if (DROP) kk = (uint32_t)(kb[r] >> (ss * LT));
+#pragma unroll
+                for (int i = 0; i < LT; ++i) {
+                    float prod = tt[0][r] * tt[i][r];
+                    if (DROP) prod = ((kk >> i) & 1u) ? prod : 0.f;
+                    node_acc[i][r] += prod;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < LT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][r] += node_acc[i][r];
+    }
+    if (g_cur >= 0) {
+#pragma unroll
+        for (int i = 0; i < LT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (hq0 + r < h) k_partials[(size_t)(c + g_cur) * lh + i * h + hq0 + r] = acc[i][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+template <int LT, int NT, bool DROP>
+__global__ void __launch_bounds__(kBwdBlock)
+backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const int *__restrict__ gid,
+                const int *__restrict__ perm, const float *__restrict__ d_k, const float *__restrict__ counts_f32,
+                int n, int d, int h, int s, int stream_len, int n_calls, float scale, int normalize, uint32_t t0,
+                uint32_t t1, const unsigned long long *__restrict__ rng, float *__restrict__ dx_out,
+                float *__restrict__ dz_partials) {
+    constexpr int DPAD = 16 * NT, ZS = DPAD + 4, GS = 17;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *zs = lds;                                         // [LT][s][16][ZS]
+    float *xt = zs + LT * s * 16 * ZS;                       // [LT][16 nodes][ZS]
+    float *gsc = xt + LT * 16 * ZS;                          // [waves][16][GS] transpose scratch
+    float *dxr = gsc + kBwdWaves * 16 * GS;                  // [waves][LT][16 nodes][DPAD]
+    __shared__ int t_node[16], t_gid[16];
+
+    const int hb = blockIdx.y;
+    const int tid = threadIdx.x;
+    stage_z<LT, NT>(z, zs, h, s, d, hb, kBwdBlock);
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, col = lane & 15;
+    const int c = blockIdx.x * 16 + col;                                   // this column's stream
+    const long long start_ll = (long long)c * stream_len;
+    const bool has_stream = start_ll < n;
+    const int start = has_stream ? (int)start_ll : 0;
+    const int end = has_stream ? (int)(start_ll + stream_len < n ? start_ll + stream_len : n) : 0;
+    const bool aligned = (d & 3) == 0;
+    DropCfg cfg;
+    if (DROP) cfg = load_cfg(rng, t0, t1);
+    const int lh = LT * h;
+    const size_t step_stride = (size_t)n * d;
+    const int hq0 = 16 * hb + 4 * q;
+    float *my_gsc = gsc + wave * 16 * GS;
+
+    f32x4 dz[LT][kSwMax][NT];
+#pragma unroll
+    for (int i = 0; i < LT; ++i)
+#pragma unroll
+        for (int sw = 0; sw < kSwMax; ++sw)
+#pragma unroll
+            for (int tc = 0; tc < NT; ++tc) dz[i][sw][tc] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dp_cur[LT][4];
+#pragma unroll
+    for (int i = 0; i < LT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dp_cur[i][r] = 0.f;
+    int g_cur = -1;
+
+    for (int t = 0; t < stream_len; ++t) {
+        __syncthreads();                                    // previous step's readers of xt / dxr are done
+        // stage the 16 x rows of this step (one per stream): thread -> (step i, node row, 16-byte chunk)
+        for (int idx = tid; idx < LT * 16 * (DPAD / 4); idx += kBwdBlock) {
+            const int ch = idx % (DPAD / 4);
+            const int row = (idx / (DPAD / 4)) % 16;
+            const int i = idx / (DPAD / 4) / 16;
+            const long long cs = (long long)(blockIdx.x * 16 + row) * stream_len;
+            const long long pp = cs + t;
+            const long long ce = cs + stream_len < n ? cs + stream_len : n;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cs < n && pp < ce) {
+                const int node = perm ? perm[pp] : (int)pp;
+                v = load4(x + i * step_stride + (size_t)node * d, d, 4 * ch, aligned);
+            }
+            *reinterpret_cast<float4 *>(xt + (i * 16 + row) * ZS + 4 * ch) = v;
+        }
+        if (tid < 16) {
+            const long long cs = (long long)(blockIdx.x * 16 + tid) * stream_len;
+            const long long pp = cs + t;
+            const long long ce = cs + stream_len < n ? cs + stream_len : n;
+            int node = -1, g = -1;
+            if (cs < n && pp < ce) {
+                node = perm ? perm[pp] : (int)pp;
+                g = gid[pp];
+            }
+            t_node[tid] = node;
+            t_gid[tid] = g;
+        }
+        __syncthreads();
+
+        const int node = t_node[col];
+        const bool valid = node >= 0;
+        const int g = valid ? t_gid[col] : g_cur;
+        if (g != g_cur) {                                   // first node of a graph in this column
+            g_cur = g;
+            float f = scale;
+            if (normalize) f /= counts_f32[g];
+#pragma unroll
+            for (int i = 0; i < LT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    dp_cur[i][r] = (hq0 + r < h) ? d_k[(size_t)g * lh + i * h + hq0 + r] * f : 0.f;
+        }
+        // operands that do not depend on s
+        float4 xv[LT][NT];                                  // B of the recompute: X_i[node = col][16tc + 4q ..]
+        float xq[LT][4][NT];                                // B of dZ: X_i[node = 4q + r][16tc + col]
+#pragma unroll
+        for (int i = 0; i < LT; ++i)
+#pragma unroll
+            for (int tc = 0; tc < NT; ++tc) {
+                xv[i][tc] = *reinterpret_cast<const float4 *>(xt + (i * 16 + col) * ZS + 16 * tc + 4 * q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xq[i][r][tc] = xt[(i * 16 + 4 * q + r) * ZS + 16 * tc + col];
+            }
+        unsigned long long kb[4] = {0, 0, 0, 0};
+        if (DROP) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                kb[r] = keep_bits(cfg, (uint32_t)(valid ? node : 0), (uint32_t)(hq0 + r), n_calls);
+        }
+        f32x4 dxa[LT][NT];                                  // dX[node = 4q + r][16tc + col], this wave's share of s
+#pragma unroll
+        for (int i = 0; i < LT; ++i)
+#pragma unroll
+            for (int tc = 0; tc < NT; ++tc) dxa[i][tc] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+        for (int sw = 0; sw < kSwMax; ++sw) {
+            const int ss = wave + kBwdWaves * sw;
+            if (ss < s) {                                   // wave-uniform
+                f32x4 tt[LT];
+#pragma unroll
+                for (int i = 0; i < LT; ++i) tt[i] = tile_zx<NT>(zs + ((i * s + ss) * 16 + col) * ZS, q, xv[i]);
+                // gradient tiles: gz (w.r.t. zx = Z0 X0^T) and gt[i] (w.r.t. t_i), rows h = 4q + r, column = node
+                f32x4 gz, gt[LT];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    uint32_t kk = 0;
+                    if (DROP) kk = (uint32_t)(kb[r] >> (ss * LT));
+                    float w[LT];
+#pragma unroll
+                    for (int i = 0; i < LT; ++i) {
+                        w[i] = dp_cur[i][r];
+                        if (DROP) w[i] = ((kk >> i) & 1u) ? w[i] : 0.f;
+                    }
+                    float a = 2.f * w[0] * tt[0][r];        // step 0 contributes keep * zx^2
+#pragma unroll
+                    for (int i = 1; i < LT; ++i) {
+                        a = fmaf(w[i], tt[i][r], a);
+                        gt[i][r] = w[i] * tt[0][r];
+                    }
+                    gz[r] = a;
+                }
+                gt[0] = gz;                                  // step 0: everything flows through Z0, X0
+                // dX_i += G_i^T Z_i[s]
+#pragma unroll
+                for (int i = 0; i < LT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float *zrow = zs + ((i * s + ss) * 16 + 4 * q + r) * ZS + col;
+#pragma unroll
+                        for (int tc = 0; tc < NT; ++tc) dxa[i][tc] = RWK_MFMA(gt[i][r], zrow[16 * tc], dxa[i][tc]);
+                    }
+                // dZ_i[s] += G_i X_i: transpose G_i (h <-> node) through this wave's scratch
+#pragma unroll
+                for (int i = 0; i < LT; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) my_gsc[(4 * q + r) * GS + col] = gt[i][r];
+                    float gtr[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gtr[r] = my_gsc[col * GS + 4 * q + r];   // G_i[h = col][node = 4q + r]
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int tc = 0; tc < NT; ++tc) dz[i][sw][tc] = RWK_MFMA(gtr[r], xq[i][r][tc], dz[i][sw][tc]);
+                }
+            }
+        }
+        // add the wavefronts' shares of dX in wavefront order and store the rows
+#pragma unroll
+        for (int i = 0; i < LT; ++i)
+#pragma unroll
+            for (int tc = 0; tc < NT; ++tc)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    dxr[((wave * LT + i) * 16 + 4 * q + r) * DPAD + 16 * tc + col] = dxa[i][tc][r];
+        __syncthreads();
+        for (int idx = tid; idx < LT * 16 * DPAD; idx += kBwdBlock) {
+            const int k = idx % DPAD;
+            const int row = (idx / DPAD) % 16;
+            const int i = idx / DPAD / 16;
+            const int nd = t_node[row];
+            if (nd < 0 || k >= d) continue;
+            float acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < kBwdWaves; ++w) acc += dxr[((w * LT + i) * 16 + row) * DPAD + k];
+            dx_out[((size_t)hb * LT + i) * step_stride + (size_t)nd * d + k] = acc;
+        }
+    }
+
+    // dZ: each wavefront owns its hidden nodes; lane holds dZ[h = 4q + r][16tc + col]
+    float *out = dz_partials + (size_t)blockIdx.x * LT * h * s * d;
+#pragma unroll
+    for (int sw = 0; sw < kSwMax; ++sw) {
+        const int ss = wave + kBwdWaves * sw;
+        if (ss >= s) continue;
+#pragma unroll
+        for (int i = 0; i < LT; ++i)
+#pragma unroll
+            for (int tc = 0; tc < NT; ++tc)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int hq = hq0 + r, k = 16 * tc + col;
+                    if (hq < h && k < d) out[(((size_t)i * h + hq) * s + ss) * d + k] = dz[i][sw][tc][r];
+                }
+    }
+}
+
+// dx[v] = sum over the hidden-graph blocks, in block order
+__global__ void __launch_bounds__(256)
+sum_blocks_kernel(const float *__restrict__ in, int n_blocks, long long v, float *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= v) return;
+    float acc = 0.f;
+    for (int b = 0; b < n_blocks; ++b) acc += in[(long long)b * v + i];
+    out[i] = acc;
+}
+
+inline int nt_of(int d) { return (d + 15) / 16; }
+
+inline size_t fwd_lds(int l, int s, int nt) { return (size_t)l * s * 16 * (16 * nt + 4) * sizeof(float); }
+inline size_t bwd_lds(int l, int s, int nt) {
+    const int dpad = 16 * nt, zs = dpad + 4;
+    return ((size_t)l * s * 16 * zs + (size_t)l * 16 * zs + kBwdWaves * 16 * 17 + (size_t)kBwdWaves * l * 16 * dpad) *
+           sizeof(float);
+}
+
+template <int LT, int NT>
+int launch_fwd(const Args &a) {
+    const int hb = (a.h + 15) / 16;
+    const int n_streams = (int)rwk_ceil_div(a.n, a.stream_len);
+    const dim3 grid((unsigned)rwk_ceil_div(n_streams, 16 * (kFwdBlock / 64)), (unsigned)hb);
+    const size_t lds = fwd_lds(LT, a.s, NT);
+    const int n_calls = (a.s * a.max_step + 14) / 15;
+#define RWK_F(DROPV)                                                                                            \
+    {                                                                                                           \
+        auto kern = forward_kernel<LT, NT, DROPV>;                                                              \
+        if (lds > 64 * 1024) {                                                                                  \
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                               (int)lds);                                                       \
+            if (e != hipSuccess) return (int)e;                                                                 \
+        }                                                                                                       \
+        hipLaunchKernelGGL(kern, grid, dim3(kFwdBlock), lds, a.stream, a.x, a.z, a.gid, a.perm, a.n, a.d, a.h, a.s, \
+                           a.stream_len, n_calls, a.t0, a.t1, a.rng, a.k_partials);                             \
+    }
+    if (a.drop) RWK_F(true) else RWK_F(false)
+#undef RWK_F
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
+template <int LT, int NT>
+int launch_bwd(const Args &a) {
+    const int hb = (a.h + 15) / 16;
+    const dim3 grid((unsigned)backward_blocks(a.n, a.stream_len), (unsigned)hb);
+    const size_t lds = bwd_lds(LT, a.s, NT);
+    const int n_calls = (a.s * a.max_step + 14) / 15;
+    float *dx_target = hb > 1 ? a.dx_partials : a.dx;
+    if (dx_target == nullptr) return RWK_E_NULL;
+#define RWK_B(DROPV)                                                                                            \
+    {                                                                                                           \
+        auto kern = backward_kernel<LT, NT, DROPV>;                                                             \
+        if (lds > 64 * 1024) {                                                                                  \
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                               (int)lds);                                                       \
+            if (e != hipSuccess) return (int)e;                                                                 \
+        }                                                                                                       \
+        hipLaunchKernelGGL(kern, grid, dim3(kBwdBlock), lds, a.stream, a.x, a.z, a.gid, a.perm, a.d_k, a.counts_f32, \
+                           a.n, a.d, a.h, a.s, a.stream_len, n_calls, a.scale, a.normalize, a.t0, a.t1, a.rng,  \
+                           dx_target, a.dz_partials);                                                           \
+    }
+    if (a.drop) RWK_B(true) else RWK_B(false)
+#undef RWK_B
+    RWK_LAUNCH_CHECK();
+    if (hb > 1) {
+        const long long v = (long long)a.max_step * a.n * a.d;
+        hipLaunchKernelGGL(sum_blocks_kernel, dim3((unsigned)rwk_ceil_div(v, 256)), dim3(256), 0, a.stream,
+                           a.dx_partials, hb, v, a.dx);
+        RWK_LAUNCH_CHECK();
+    }
+    return RWK_OK;
+}
+
+template <int LT>
+int by_nt(const Args &a, bool bwd) {
+    switch (nt_of(a.d)) {
+        case 1: return bwd ? launch_bwd<LT, 1>(a) : launch_fwd<LT, 1>(a);
+        case 2: return bwd ? launch_bwd<LT, 2>(a) : launch_fwd<LT, 2>(a);
+        case 3:
+        case 4: return bwd ? launch_bwd<LT, 4>(a) : launch_fwd<LT, 4>(a);
+    }
+    return RWK_E_UNSUPPORTED;
+}
+
+int by_l(const Args &a, bool bwd) {
+    switch (a.max_step) {
+        case 1: return by_nt<1>(a, bwd);
+        case 2: return by_nt<2>(a, bwd);
+        case 3: return by_nt<3>(a, bwd);
+        case 4: return by_nt<4>(a, bwd);
+    }
+    return RWK_E_UNSUPPORTED;
+}
+
+}  // namespace
+
+bool supported(int64_t d, int64_t h, int64_t s, int64_t max_step) {
+    if (d <= 4 || d > 64 || h < 1 || h > 64 || max_step < 1 || max_step > 4) return false;
+    if (s < 1 || s > kBwdWaves * kSwMax || s * max_step > 45) return false;
+    int nt = nt_of((int)d);
+    if (nt == 3) nt = 4;
+    return bwd_lds((int)max_step, (int)s, nt) + 256 <= kLdsBudget;
+}
+
+int64_t backward_blocks(int64_t n, int64_t stream_len) { return rwk_ceil_div(rwk_ceil_div(n, stream_len), 16); }
+
+int64_t dx_partials_size(int64_t n, int64_t d, int64_t h, int64_t max_step) {
+    const int64_t hb = (h + 15) / 16;
+    return hb > 1 ? hb * max_step * n * d : 0;
+}
+
+int forward(const Args &a) { return by_l(a, false); }
+int backward(const Args &a) { return by_l(a, true); }
+
+}  // namespace rwk_mfma

@@ -34,8 +34,16 @@ def _pow2_ceil(v: int) -> int:
     return p
 
 
-def choose_stream_len(n_nodes: int, n_hidden: int) -> int:
-    """Sorted positions walked sequentially by one lane group of the fused kernels."""
+def choose_stream_len(n_nodes: int, n_hidden: int, path: int = 1) -> int:
+    """Sorted positions walked sequentially by one lane group of the fused kernels.
+    ``path``: kernel family as reported by ``rwk_fused_path`` (2 = matrix-core kernels)."""
+    if path == 2:
+        # forward workgroups hold 128 streams for one block of 16 hidden graphs; aim at m full rounds of
+        # 256 workgroups (one per CU: the Z slab takes most of the LDS) with 8..32 positions per stream
+        hb = -(-n_hidden // 16)
+        per_round = 128 * 256 // hb
+        m = max(1, round(n_nodes / (per_round * 16)))
+        return max(4, -(-n_nodes // (per_round * m)))
     # Workgroups of 256 threads hold 256/hp streams; 256 CUs x 4 resident workgroups = 1024 slots.
     # Aim at a whole number m of full rounds of 1024 workgroups with about 20 positions per stream:
     # a last round that is mostly empty costs as much as a full one.
@@ -99,7 +107,7 @@ class _RWKernelLayer(torch.autograd.Function):
                        "rwk_hidden_forward")
             for i in range(1, steps):
                 st.spmm(xs[i - 1], xs[i])                                        # model.py:55
-            stream_len = choose_stream_len(n, n_hidden)
+            stream_len = choose_stream_len(n, n_hidden, lib.rwk_fused_path(d, n_hidden, s, steps))
             slots = lib.rwk_fused_k_partials_size(n, stream_len, g, n_hidden, steps)
             k_partials = torch.empty(slots, dtype=torch.float32, device=dev)
             _lib.check(lib.rwk_fused_forward(xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm),
@@ -132,10 +140,12 @@ class _RWKernelLayer(torch.autograd.Function):
             if n_part <= 0:
                 raise NotImplementedError("unsupported hyper-parameters for the fused backward kernel")
             dz_partials = torch.empty((n_part, steps * n_hidden * s * d), dtype=torch.float32, device=dev)
+            ws_n = lib.rwk_fused_backward_workspace(n, d, n_hidden, s, steps)
+            ws = torch.empty(ws_n, dtype=torch.float32, device=dev) if ws_n else None
             _lib.check(lib.rwk_fused_backward(xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm),
                                               d_k.data_ptr(), st.counts_f32.data_ptr(), n, d, n_hidden, s, steps,
                                               stream_len, drop, int(normalize), _lib.ptr(rng_used),
-                                              dx.data_ptr(), dz_partials.data_ptr(), stream),
+                                              dx.data_ptr(), dz_partials.data_ptr(), _lib.ptr(ws), stream),
                        "rwk_fused_backward")
             for i in range(steps - 1, 0, -1):
                 st.spmm(dx[i], dx[i - 1], transpose=True, accumulate=True)      # dX[i-1] += A^T dX[i]

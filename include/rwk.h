@@ -157,7 +157,16 @@ int rwk_fused_backward(const float *x, const float *z, const int32_t *gid, const
                        const float *d_k, const float *counts_f32, int64_t n, int64_t d, int64_t h,
                        int64_t s, int64_t max_step, int64_t stream_len, float drop_p,
                        int normalize, const uint64_t *rng, float *dx, float *dz_partials,
-                       rwk_stream_t stream);
+                       float *workspace, rwk_stream_t stream);
+
+/* Floats of `workspace` rwk_fused_backward needs (0: pass NULL).  Non-zero only on the matrix-core
+ * path with more than 16 hidden graphs, where each block of 16 hidden graphs writes its own share
+ * of dx and the shares are then added in block order. */
+int64_t rwk_fused_backward_workspace(int64_t n, int64_t d, int64_t h, int64_t s, int64_t max_step);
+
+/* Which kernel family serves these hyper-parameters: 1 = register-resident vector-ALU kernels
+ * (hidden_dim <= 4), 2 = fp32 matrix-core kernels (hidden_dim 5..64), 0 = generic LDS kernels. */
+int rwk_fused_path(int64_t d, int64_t h, int64_t s, int64_t max_step);
 
 /* ---------------------------------------------------------------------------------------
  * Input projection  X0 = sigmoid(features W^T + b)   replaces model.py:43 for narrow inputs

@@ -105,3 +105,4 @@ def test_stream_length_rule():
     assert choose_stream_len(307842, 16) == 19          # 1013 workgroups: one round of the 1024 slots
     assert choose_stream_len(50_000_000, 16) == 20
     assert choose_stream_len(103008, 64) == 26
+    assert choose_stream_len(103008, 64, path=2) == 13   # matrix-core kernels: 248 forward workgroups x 4 blocks
