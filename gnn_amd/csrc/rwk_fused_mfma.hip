@@ -233,11 +233,6 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
 
     const int lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, col = lane & 15;
-    const int c = blockIdx.x * 16 + col;                                   // this column's stream
-    const long long start_ll = (long long)c * stream_len;
-    const bool has_stream = start_ll < n;
-    const int start = has_stream ? (int)start_ll : 0;
-    const int end = has_stream ? (int)(start_ll + stream_len < n ? start_ll + stream_len : n) : 0;
     const bool aligned = (d & 3) == 0;
     DropCfg cfg;
     if (DROP) cfg = load_cfg(rng, t0, t1);
@@ -260,36 +255,60 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
         for (int r = 0; r < 4; ++r) dp_cur[i][r] = 0.f;
     int g_cur = -1;
 
-    for (int t = 0; t < stream_len; ++t) {
-        __syncthreads();                                    // previous step's readers of xt / dxr are done
-        // stage the 16 x rows of this step (one per stream): thread -> (step i, node row, 16-byte chunk)
-        for (int idx = tid; idx < LT * 16 * (DPAD / 4); idx += kBwdBlock) {
+    // The 16 x rows of a step (one per stream) are fetched one step ahead into registers, so that their
+    // global-memory latency overlaps the MFMAs of the current step: thread -> (step i, node row, 16-byte chunk).
+    constexpr int kChunks = LT * 16 * (DPAD / 4);
+    constexpr int kLoads = (kChunks + kBwdBlock - 1) / kBwdBlock;
+    float4 pre[kLoads];
+    int pre_node = -1, pre_gid = -1;
+    auto prefetch = [&](int t) {
+#pragma unroll
+        for (int k = 0; k < kLoads; ++k) {
+            const int idx = tid + k * kBwdBlock;
             const int ch = idx % (DPAD / 4);
             const int row = (idx / (DPAD / 4)) % 16;
-            const int i = idx / (DPAD / 4) / 16;
+            const int i = (idx / (DPAD / 4) / 16) % LT;
             const long long cs = (long long)(blockIdx.x * 16 + row) * stream_len;
             const long long pp = cs + t;
             const long long ce = cs + stream_len < n ? cs + stream_len : n;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (cs < n && pp < ce) {
-                const int node = perm ? perm[pp] : (int)pp;
-                v = load4(x + i * step_stride + (size_t)node * d, d, 4 * ch, aligned);
-            }
-            *reinterpret_cast<float4 *>(xt + (i * 16 + row) * ZS + 4 * ch) = v;
+            const bool ok = idx < kChunks && cs < n && pp < ce;
+            const long long pc = ok ? pp : 0;
+            const int node = perm ? perm[pc] : (int)pc;
+            const float4 v = load4(x + i * step_stride + (size_t)node * d, d, 4 * ch, aligned);
+            pre[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (tid < 16) {
             const long long cs = (long long)(blockIdx.x * 16 + tid) * stream_len;
             const long long pp = cs + t;
             const long long ce = cs + stream_len < n ? cs + stream_len : n;
-            int node = -1, g = -1;
-            if (cs < n && pp < ce) {
-                node = perm ? perm[pp] : (int)pp;
-                g = gid[pp];
+            const bool ok = cs < n && pp < ce;
+            const long long pc = ok ? pp : 0;
+            const int node = perm ? perm[pc] : (int)pc;
+            const int g = gid[pc];
+            pre_node = ok ? node : -1;
+            pre_gid = ok ? g : -1;
+        }
+    };
+    prefetch(0);
+
+    for (int t = 0; t < stream_len; ++t) {
+        __syncthreads();                                    // previous step's readers of xt / dxr are done
+#pragma unroll
+        for (int k = 0; k < kLoads; ++k) {
+            const int idx = tid + k * kBwdBlock;
+            if (idx < kChunks) {
+                const int ch = idx % (DPAD / 4);
+                const int row = (idx / (DPAD / 4)) % 16;
+                const int i = idx / (DPAD / 4) / 16;
+                *reinterpret_cast<float4 *>(xt + (i * 16 + row) * ZS + 4 * ch) = pre[k];
             }
-            t_node[tid] = node;
-            t_gid[tid] = g;
+        }
+        if (tid < 16) {
+            t_node[tid] = pre_node;
+            t_gid[tid] = pre_gid;
         }
         __syncthreads();
+        if (t + 1 < stream_len) prefetch(t + 1);
 
         const int node = t_node[col];
         const bool valid = node >= 0;
