@@ -34,6 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0
+FP32_PEAK_TFLOPS = 157.3      # dense fp32 MFMA peak = fp32 vector peak
 
 
 def parse_args():
@@ -50,6 +51,16 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-sample-graphs", type=int, default=128)
+    ap.add_argument("--kernels-only", action="store_true",
+                    help="no training loop: time the hand-written kernels on the (tiled) batch and print them")
+    ap.add_argument("--roofline-scale", type=int, default=1,
+                    help="with --kernels-only: tile the batch this many times on the device, so that the working "
+                         "set leaves the 256 MB Infinity Cache")
+    ap.add_argument("--dropout", type=float, default=None, help="override the configuration's dropout rate")
+    ap.add_argument("--calibrate", action="store_true",
+                    help="with --kernels-only: also launch a 1 GiB elementwise read+write, the known byte count "
+                         "the FETCH_SIZE / WRITE_SIZE counter passes are calibrated on")
+    ap.add_argument("--only", default="", help="with --kernels-only: comma-separated kernel classes to launch")
     return ap.parse_args()
 
 
@@ -107,9 +118,27 @@ class Trainer:
         self.g_opt.replay()
 
 
-def time_kernels(model, batch_t, hp, iters=50):
+def tile_batch(batch_t, k):
+    """k copies of a resident batch as one block-diagonal batch, built on the device (the roofline-sized
+    variant of a configuration: same graphs, working set far beyond the 256 MB Infinity Cache)."""
+    adj, feats, gi, y = batch_t
+    if k <= 1:
+        return batch_t
+    dev = feats.device
+    n = adj.shape[0]
+    g = int(gi.max().item()) + 1
+    idx, val = adj._indices(), adj._values()
+    node_off = torch.arange(k, device=dev, dtype=torch.int64) * n
+    idx_k = (idx[:, None, :] + node_off[None, :, None]).reshape(2, -1)          # stays row-major sorted
+    adj_k = torch.sparse_coo_tensor(idx_k, val.repeat(k), (n * k, n * k))
+    graph_off = torch.arange(k, device=dev, dtype=torch.int64) * g
+    gi_k = (gi[None, :] + graph_off[:, None]).reshape(-1)
+    return adj_k, feats.repeat(k, 1), gi_k, y.repeat(k)
+
+
+def time_kernels(batch_t, hp, budget_ms=150.0, only=None):
     """Average launch duration of each hand-written kernel class, by launching it back to back through the
-    C ABI between two events on the launch stream, and its algorithmic HBM bytes."""
+    C ABI between two events on the launch stream, with its algorithmic HBM bytes and flops."""
     from gnn_amd import _lib, get_structure
     from gnn_amd.function import choose_stream_len
     lib = _lib.load()
@@ -120,14 +149,16 @@ def time_kernels(model, batch_t, hp, iters=50):
     h, s, d, steps = hp["hidden_graphs"], hp["size_hidden_graphs"], hp["hidden_dim"], hp["max_step"]
     p = float(hp["dropout"])
     stream = _lib.current_stream(dev)
+    path = lib.rwk_fused_path(d, h, s, steps)
     xs = torch.rand((steps, n, d), device=dev)
     z = torch.rand((steps, h, s, d), device=dev)
     dk = torch.randn((g, steps * h), device=dev)
     rng = torch.tensor([12345, 7], dtype=torch.int64, device=dev)
-    stream_len = choose_stream_len(n, h, lib.rwk_fused_path(d, h, s, steps))
+    stream_len = choose_stream_len(n, d, h, s, steps)
+    stream_len_b = choose_stream_len(n, d, h, s, steps, backward=True)
     n_streams = lib.rwk_fused_n_streams(n, stream_len)
     k_part = torch.empty(lib.rwk_fused_k_partials_size(n, stream_len, g, h, steps), device=dev)
-    n_part = lib.rwk_fused_dz_partials_count(n, stream_len, d, h, s, steps)
+    n_part = lib.rwk_fused_dz_partials_count(n, stream_len_b, d, h, s, steps)
     dz_part = torch.empty((n_part, steps, h, s, d), device=dev)
     dx = torch.empty_like(xs)
     ws_n = lib.rwk_fused_backward_workspace(n, d, h, s, steps)
@@ -143,26 +174,44 @@ def time_kernels(model, batch_t, hp, iters=50):
 
     def run_bwd():
         _lib.check(lib.rwk_fused_backward(xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm),
-                                          dk.data_ptr(), st.counts_f32.data_ptr(), n, d, h, s, steps, stream_len, p,
+                                          dk.data_ptr(), st.counts_f32.data_ptr(), n, d, h, s, steps, stream_len_b, p,
                                           0, rng.data_ptr(), dx.data_ptr(), dz_part.data_ptr(), _lib.ptr(ws), stream),
                    "bwd")
 
     lh = steps * h
+    # algorithmic HBM bytes per launch (fp32 and int32 are 4 bytes):
+    #   SpMM:      values + columns + row pointers + x read once + y written once
+    #   forward:   X_0..X_{L-1} read once, one graph id per node, K partial slots written, Z once
+    #   backward:  X read + dX written, graph ids, dK, the per-workgroup dZ partial rows written
     bytes_ = {
         "spmm_csr": st.spmm_bytes(d),
         "fused_forward": steps * n * d * 4 + n * 4 + (n_streams + g) * lh * 4 + steps * h * s * d * 4,
         "fused_backward": 2 * steps * n * d * 4 + n * 4 + g * lh * 4 + n_part * steps * h * s * d * 4,
     }
+    # flops: one contraction T_i = Z_i X_i^T per step forward; recompute + dX + dZ contractions backward
     flops = {
         "spmm_csr": 2 * st.nnz * d,
         "fused_forward": 2 * h * s * d * n * steps + 3 * steps * h * s * n,
         "fused_backward": 3 * 2 * h * s * d * n * steps + 8 * steps * h * s * n,
     }
+    # what limits the kernel: the matrix-core kernels (hidden_dim > 4) are priced against the dense fp32 MFMA
+    # peak; everything else against HBM
+    bound = {"spmm_csr": "hbm", "fused_forward": "mfma" if path == 2 else "hbm",
+             "fused_backward": "mfma" if path == 2 else "hbm"}
     out = {}
     for name, fn in (("spmm_csr", run_spmm), ("fused_forward", run_fwd), ("fused_backward", run_bwd)):
-        for _ in range(5):
-            fn()
+        if only and name not in only:
+            continue
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        one = max(e0.elapsed_time(e1), 1e-3)
+        iters = int(min(50, max(3, budget_ms / one)))
+        for _ in range(min(5, iters)):
+            fn()
         e0.record()
         for _ in range(iters):
             fn()
@@ -170,10 +219,34 @@ def time_kernels(model, batch_t, hp, iters=50):
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / iters
         gbs = bytes_[name] / (us * 1e-6) / 1e9
-        out[name] = {"us": round(us, 3), "bytes": int(bytes_[name]), "GB/s": round(gbs, 1),
-                     "frac_hbm": round(gbs / HBM_PEAK_GBS, 4),
-                     "TFLOP/s": round(flops[name] / (us * 1e-6) / 1e12, 3)}
+        tfs = flops[name] / (us * 1e-6) / 1e12
+        out[name] = {"us": round(us, 3), "launches": iters, "bytes": int(bytes_[name]), "flops": int(flops[name]),
+                     "GB/s": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4), "TFLOP/s": round(tfs, 3),
+                     "frac_fp32_peak": round(tfs / FP32_PEAK_TFLOPS, 4), "bound": bound[name]}
+    out["_shape"] = {"nodes": n, "nnz": st.nnz, "graphs": g, "stream_len": [stream_len, stream_len_b],
+                     "fused_path": {0: "generic", 1: "register", 2: "mfma"}[path]}
     return out
+
+
+def roofline_of(kern, name, traffic=None):
+    k = kern[name]
+    if k["bound"] == "mfma":
+        return {"kernel": name, "bound": "mfma", "achieved": k["TFLOP/s"], "peak": FP32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": k["frac_fp32_peak"], "traffic": traffic,
+                "hbm_GB/s": k["GB/s"], "us": k["us"]}
+    return {"kernel": name, "bound": "hbm", "achieved": k["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": k["frac_hbm"], "traffic": traffic, "fp32_TFLOP/s": k["TFLOP/s"],
+            "frac_fp32_peak": k["frac_fp32_peak"], "us": k["us"]}
+
+
+def load_traffic(config, scale):
+    """HBM bytes per launch from the committed counter passes (profiles/traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate rocprofv3 --pmc runs of `bench.py --kernels-only`), or {}."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(f"{config}@{scale}", {})
+    except (OSError, ValueError):
+        return {}
 
 
 def cpu_baseline(batch, hp, n_graphs, budget_s=20.0):
@@ -240,9 +313,28 @@ def main():
     from gnn_amd.synth import CONFIGS, config_batch
 
     cfg = CONFIGS[args.config]
-    hp = cfg["hp"]
+    hp = dict(cfg["hp"])
+    if args.dropout is not None:
+        hp["dropout"] = args.dropout
     batch = config_batch(args.config, seed=1 + rank, scale=args.scale)     # each rank its own graphs
     batch_t = batch.to_torch(dev)
+
+    if args.kernels_only:
+        only = [k for k in args.only.split(",") if k] or None
+        kern = time_kernels(tile_batch(batch_t, args.roofline_scale), hp, only=only)
+        if args.calibrate:
+            a = torch.zeros(1 << 28, device=dev)
+            b = torch.empty_like(a)
+            for _ in range(3):
+                torch.add(a, 1.0, out=b)
+            torch.cuda.synchronize()
+        traffic = load_traffic(args.config, args.roofline_scale)
+        shape = kern.pop("_shape")
+        print(json.dumps({"config": args.config, "roofline_scale": args.roofline_scale, "shape": shape,
+                          "dropout": hp["dropout"], "kernels": kern,
+                          "roofline": [roofline_of(kern, k, traffic.get(k, {}).get("hbm_bytes")) for k in kern]}),
+              flush=True)
+        return
 
     torch.manual_seed(0)
     model = RW_NN(hp["input_dim"], hp["max_step"], hp["hidden_graphs"], hp["size_hidden_graphs"], hp["hidden_dim"],
@@ -304,11 +396,12 @@ def main():
             "final_loss": round(loss, 5),
         }
         if not args.no_kernel_timing:
-            kern = time_kernels(model, batch_t, hp)
+            kern = time_kernels(batch_t, hp)
+            result["kernel_shape"] = kern.pop("_shape")
             dom = max(kern, key=lambda k: kern[k]["us"])
+            traffic = load_traffic(args.config, 1)
             result["kernels"] = kern
-            result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["GB/s"], "peak": HBM_PEAK_GBS,
-                                  "unit": "GB/s", "frac": kern[dom]["frac_hbm"], "traffic": None}
+            result["roofline"] = roofline_of(kern, dom, traffic.get(dom, {}).get("hbm_bytes"))
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(batch, hp, args.cpu_sample_graphs)
         print(json.dumps(result), flush=True)

@@ -37,6 +37,7 @@ SIGNATURES = {
                                    _P, _P, _P, _P, _P]),
     "rwk_fused_backward_workspace": (_I64, [_I64, _I64, _I64, _I64, _I64]),
     "rwk_fused_path": (c_int, [_I64, _I64, _I64, _I64]),
+    "rwk_fused_stream_len": (_I64, [_I64, _I64, _I64, _I64, _I64, c_int]),
     "rwk_project_forward": (c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
     "rwk_project_backward_blocks": (_I64, [_I64, _I64]),
     "rwk_project_backward": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P]),

@@ -551,6 +551,20 @@ int64_t dx_partials_size(int64_t n, int64_t d, int64_t h, int64_t max_step) {
     return hb > 1 ? hb * max_step * n * d : 0;
 }
 
+// Forward workgroups hold 128 streams for one block of 16 hidden graphs, one workgroup per CU (the Z slab
+// takes most of the LDS): aim at m full rounds of 256 workgroups with about 16 positions per stream, and up
+// to 64 in very large batches, so that the per-workgroup dZ partial rows stay small next to the X rows read.
+int64_t stream_len(int64_t n, int64_t h) {
+    const int64_t hb = (h + 15) / 16;
+    const int64_t per_round = 128 * 256 / hb;
+    int64_t target = n / (per_round * 4);
+    target = target < 16 ? 16 : (target > 64 ? 64 : target);
+    int64_t m = (n + per_round * target / 2) / (per_round * target);
+    if (m < 1) m = 1;
+    const int64_t len = rwk_ceil_div(n, per_round * m);
+    return len < 4 ? 4 : len;
+}
+
 int forward(const Args &a) { return by_l(a, false); }
 int backward(const Args &a) { return by_l(a, true); }
 

@@ -26,6 +26,8 @@ struct Args {
 bool supported(int64_t d, int64_t h, int64_t s, int64_t max_step);
 // workgroups of the backward launch = rows of dz_partials
 int64_t backward_blocks(int64_t n, int64_t stream_len, int64_t h);
+// positions per stream that fill the chip in whole rounds of resident workgroups
+int64_t stream_len(int64_t n, int64_t h, int64_t s, int64_t max_step, bool bwd);
 int forward(const Args &a);
 int backward(const Args &a);
 

@@ -18,7 +18,7 @@ constexpr int kBlock = 256;
 constexpr int DP = 4;
 // Waves per SIMD the backward kernel is compiled for: L*S*4 dZ accumulators + L*S*4 rows of Z must fit.
 // 4 (<= 128 VGPRs, four 256-thread workgroups per CU) up to L*S = 10, then 2, then 1.
-constexpr int bwd_waves_per_simd(int ls) { return ls <= 10 ? 4 : (ls <= 24 ? 2 : 1); }
+constexpr int bwd_waves_per_simd(int ls) { return ls <= 10 ? 3 : (ls <= 20 ? 2 : 1); }
 
 struct DropCfg {
     uint32_t t0, t1, seed_lo, key_hi, off_lo;
@@ -257,11 +257,6 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
         load_tile<LT>(tile, x, gid, perm, my_p, end, has_stream, d, step_stride);
         __syncthreads();
         const int my_node = tile.node[tid];
-        float mine[LT][DP];                               // dX rows of this lane's own slot
-#pragma unroll
-        for (int i = 0; i < LT; ++i)
-#pragma unroll
-            for (int k = 0; k < DP; ++k) mine[i][k] = 0.f;
         // every lane of the wavefront runs all hp iterations: the DPP butterfly needs them all
         const int jmax = stream_len - base < hp ? stream_len - base : hp;
 #pragma unroll 2
@@ -317,25 +312,29 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                     }
                 }
             }
-            // sum the dX rows over the hidden graphs (the hp lanes of this stream); lane j keeps them
+            // sum the dX rows over the hidden graphs (the hp lanes of this stream); lane j puts the totals
+            // where the x rows of slot j were: the lanes of a stream share a wavefront, so all of them have
+            // read those rows by now
 #pragma unroll
-            for (int i = 0; i < LT; ++i)
+            for (int i = 0; i < LT; ++i) {
+                float tot[DP];
 #pragma unroll
-                for (int k = 0; k < DP; ++k) {
-                    const float tot = rwk_group_sum(dxr[i][k], hp);
-                    mine[i][k] = lane_h == j ? tot : mine[i][k];
-                }
+                for (int k = 0; k < DP; ++k) tot[k] = rwk_group_sum(dxr[i][k], hp);
+                if (lane_h == j) tile.x[i][group0 + j] = make_float4(tot[0], tot[1], tot[2], tot[3]);
+            }
         }
         if (my_node >= 0) {                               // coalesced: hp lanes store hp consecutive rows
 #pragma unroll
             for (int i = 0; i < LT; ++i) {
+                const float4 mv = tile.x[i][tid];         // written by a lane of this wavefront
+                const float mine_i[DP] = {mv.x, mv.y, mv.z, mv.w};
                 float *row = dx + i * step_stride + (size_t)my_node * d;
                 if (d == DP) {
-                    *reinterpret_cast<float4 *>(row) = make_float4(mine[i][0], mine[i][1], mine[i][2], mine[i][3]);
+                    *reinterpret_cast<float4 *>(row) = mv;
                 } else {
 #pragma unroll
                     for (int k = 0; k < DP; ++k)
-                        if (k < d) row[k] = mine[i][k];
+                        if (k < d) row[k] = mine_i[k];
                 }
             }
         }
@@ -433,6 +432,19 @@ bool supported(int64_t d, int64_t h, int64_t s, int64_t max_step) {
 int64_t backward_blocks(int64_t n, int64_t stream_len, int64_t h) {
     const int hp = pow2_ceil((int)h);
     return rwk_ceil_div(rwk_ceil_div(n, stream_len), kBlock / hp);
+}
+
+// Workgroups of kBlock threads hold kBlock/hp streams; a CU keeps 4 forward workgroups resident and
+// bwd_waves_per_simd() backward ones.  Aim at a whole number m of full rounds over the 256 CUs with about
+// 20 positions per stream: a last round that is mostly empty costs as much as a full one.
+int64_t stream_len(int64_t n, int64_t h, int64_t s, int64_t max_step, bool bwd) {
+    const int hp = pow2_ceil((int)h);
+    const int64_t resident = bwd ? bwd_waves_per_simd((int)(s * max_step)) : 4;
+    const int64_t per_round = (int64_t)(kBlock / hp) * 256 * resident;
+    int64_t m = (n + per_round * 10) / (per_round * 20);
+    if (m < 1) m = 1;
+    const int64_t len = rwk_ceil_div(n, per_round * m);
+    return len < 8 ? 8 : len;
 }
 
 int forward(const Args &a) { return by_l(a, false); }

@@ -23,34 +23,12 @@ __all__ = ["rw_kernel_layer", "rw_kernel_layer_projected", "choose_stream_len", 
 
 FUSED_PROJECTION_MAX_INPUT_DIM = 8
 
-# lanes we want in flight: 256 CUs x 4 SIMDs x 4 wavefronts x 64 lanes
-_TARGET_LANES = 256 * 4 * 4 * 64
-
-
-def _pow2_ceil(v: int) -> int:
-    p = 1
-    while p < v:
-        p *= 2
-    return p
-
-
-def choose_stream_len(n_nodes: int, n_hidden: int, path: int = 1) -> int:
-    """Sorted positions walked sequentially by one lane group of the fused kernels.
-    ``path``: kernel family as reported by ``rwk_fused_path`` (2 = matrix-core kernels)."""
-    if path == 2:
-        # forward workgroups hold 128 streams for one block of 16 hidden graphs; aim at m full rounds of
-        # 256 workgroups (one per CU: the Z slab takes most of the LDS) with 8..32 positions per stream
-        hb = -(-n_hidden // 16)
-        per_round = 128 * 256 // hb
-        m = max(1, round(n_nodes / (per_round * 16)))
-        return max(4, -(-n_nodes // (per_round * m)))
-    # Workgroups of 256 threads hold 256/hp streams; 256 CUs x 4 resident workgroups = 1024 slots.
-    # Aim at a whole number m of full rounds of 1024 workgroups with about 20 positions per stream:
-    # a last round that is mostly empty costs as much as a full one.
-    hp = _pow2_ceil(n_hidden)
-    per_round = (256 // hp) * 1024
-    m = max(1, round(n_nodes / (per_round * 20)))
-    return max(8, -(-n_nodes // (per_round * m)))
+def choose_stream_len(n_nodes: int, hidden_dim: int, n_hidden: int, size_hidden: int, max_step: int,
+                      backward: bool = False) -> int:
+    """Sorted positions walked sequentially by one lane group of the fused forward (or backward) kernel:
+    the library's own rule, which knows how many workgroups of each kernel a CU keeps resident."""
+    return int(_lib.load().rwk_fused_stream_len(n_nodes, hidden_dim, n_hidden, size_hidden, max_step,
+                                                int(bool(backward))))
 
 
 def _reduce_rows(lib, partials2d, stream):
@@ -107,7 +85,7 @@ class _RWKernelLayer(torch.autograd.Function):
                        "rwk_hidden_forward")
             for i in range(1, steps):
                 st.spmm(xs[i - 1], xs[i])                                        # model.py:55
-            stream_len = choose_stream_len(n, n_hidden, lib.rwk_fused_path(d, n_hidden, s, steps))
+            stream_len = choose_stream_len(n, d, n_hidden, s, steps)
             slots = lib.rwk_fused_k_partials_size(n, stream_len, g, n_hidden, steps)
             k_partials = torch.empty(slots, dtype=torch.float32, device=dev)
             _lib.check(lib.rwk_fused_forward(xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm),
@@ -118,7 +96,7 @@ class _RWKernelLayer(torch.autograd.Function):
                                             st.counts_f32.data_ptr(), g, n_hidden, steps, stream_len, drop,
                                             int(bool(normalize)), k.data_ptr(), stream), "rwk_fused_reduce")
         ctx.st = st
-        ctx.cfg = (steps, bool(normalize), drop, stream_len, projected)
+        ctx.cfg = (steps, bool(normalize), drop, projected)
         ctx.save_for_backward(xs, z, ah, adj_hidden_c, rng_used, inp_c if projected else None, w_c)
         return k
 
@@ -128,9 +106,10 @@ class _RWKernelLayer(torch.autograd.Function):
         lib = _lib.load()
         xs, z, ah, adj_hidden_c, rng_used, feats, w_c = ctx.saved_tensors
         st: GraphStructure = ctx.st
-        steps, normalize, drop, stream_len, projected = ctx.cfg
+        steps, normalize, drop, projected = ctx.cfg
         _, n_hidden, s, d = z.shape
         n = st.n
+        stream_len = choose_stream_len(n, d, n_hidden, s, steps, backward=True)
         dev = xs.device
         with torch.cuda.device(dev):
             stream = _lib.current_stream(dev)

@@ -168,6 +168,12 @@ int64_t rwk_fused_backward_workspace(int64_t n, int64_t d, int64_t h, int64_t s,
  * (hidden_dim <= 4), 2 = fp32 matrix-core kernels (hidden_dim 5..64), 0 = generic LDS kernels. */
 int rwk_fused_path(int64_t d, int64_t h, int64_t s, int64_t max_step);
 
+/* Recommended stream_len for rwk_fused_forward (backward = 0) or rwk_fused_backward (backward = 1):
+ * the number of sorted positions per stream that fills the 256 CUs in whole rounds of resident
+ * workgroups.  The two launches may use different values; any stream_len >= 1 is valid, and the
+ * partial-buffer sizes above must be queried with the value actually passed. */
+int64_t rwk_fused_stream_len(int64_t n, int64_t d, int64_t h, int64_t s, int64_t max_step, int backward);
+
 /* ---------------------------------------------------------------------------------------
  * Input projection  X0 = sigmoid(features W^T + b)   replaces model.py:43 for narrow inputs
  * (input_dim <= 8; wider inputs go through a GEMM library and only the sigmoid is applied here)

@@ -101,8 +101,12 @@ def test_spmm_schedule_rule():
 
 def test_stream_length_rule():
     from gnn_amd.function import choose_stream_len
-    assert choose_stream_len(1168, 16) == 8
-    assert choose_stream_len(307842, 16) == 19          # 1013 workgroups: one round of the 1024 slots
-    assert choose_stream_len(50_000_000, 16) == 20
-    assert choose_stream_len(103008, 64) == 26
-    assert choose_stream_len(103008, 64, path=2) == 13   # matrix-core kernels: 248 forward workgroups x 4 blocks
+    assert choose_stream_len(1168, 4, 16, 5, 2) == 8
+    assert choose_stream_len(307842, 4, 16, 5, 2) == 19          # 1013 workgroups: one round of the 1024 slots
+    assert choose_stream_len(307842, 4, 16, 5, 2, backward=True) == 26   # 3 resident workgroups per CU
+    assert choose_stream_len(50_000_000, 4, 16, 5, 2) == 20
+    assert choose_stream_len(103008, 4, 64, 5, 2) == 26
+    # matrix-core kernels: 248 forward workgroups x 4 blocks of 16 hidden graphs
+    assert choose_stream_len(103008, 64, 64, 10, 2) == 13
+    assert choose_stream_len(103008, 64, 64, 10, 2, backward=True) == 13
+    assert choose_stream_len(0, 4, 16, 5, 2) == 0
