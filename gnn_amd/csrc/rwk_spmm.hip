@@ -80,6 +80,179 @@ spmm_csr_kernel(const int32_t *__restrict__ crow, const int32_t *__restrict__ co
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Tile kernel for sparse rows (mean degree well below 64): a workgroup owns 256/VEC consecutive rows,
+// hence one contiguous range of stored entries.  Phase 1 walks that range entry-parallel: column and
+// value are read coalesced, each entry's x row is gathered by VEC lanes (every gather of a pass is in
+// flight at once) and parked in LDS.  Phase 2 walks it row-parallel: the row's lanes add its entries
+// from LDS in stored order (an fmaf chain, as a sequential CSR loop would).  Rows with more than
+// kLongRow entries in the tile (power-law hubs) are summed by the whole workgroup instead, in a fixed
+// tree order.  y is written coalesced, one 16-byte chunk per lane.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kTileBytes = 16 * 1024;
+constexpr int kLongRow = 64;
+
+template <int VEC, bool ALIGNED>
+__global__ void __launch_bounds__(kBlock)
+spmm_tile_kernel(const int32_t *__restrict__ crow, const int32_t *__restrict__ col, const float *__restrict__ val,
+                 int n, int d, const float *__restrict__ x, float *__restrict__ y, int accumulate) {
+    constexpr int RPW = kBlock / VEC;                   // rows per workgroup = entry slots per pass
+    constexpr int ET = kTileBytes / (16 * VEC);         // entries per LDS tile
+    constexpr int PASSES = ET / RPW;
+    constexpr int GP = PASSES < 4 ? PASSES : 4;         // passes whose loads are issued together
+    __shared__ float4 s_x[ET * VEC];
+    __shared__ float s_val[ET];
+    __shared__ float4 s_red[kBlock];
+    __shared__ int s_crow[RPW + 1];
+    __shared__ int s_long[RPW];
+    __shared__ int s_nlong;
+
+    const int tid = threadIdx.x;
+    const int sub = tid % VEC, slot = tid / VEC;
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give every XCD one contiguous
+    // eighth of the row blocks, so that neighbouring blocks (rows of the same graph, which gather the same
+    // x rows) meet in one L2.
+    const int per_xcd = gridDim.x / 8;
+    const int lb = (int)blockIdx.x < per_xcd * 8 ? ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8
+                                                 : (int)blockIdx.x;
+    const int r0 = lb * RPW;
+    const int nrows = n - r0 < RPW ? n - r0 : RPW;
+    for (int i = tid; i <= nrows; i += kBlock) s_crow[i] = crow[r0 + i];
+    if (tid == 0) s_nlong = 0;
+    __syncthreads();
+    const int e0 = s_crow[0], e1 = s_crow[nrows];
+    const bool has_row = slot < nrows;
+    const int beg = has_row ? s_crow[slot] : 0;
+    const int end = has_row ? s_crow[slot + 1] : 0;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int cb = e0; cb < e1; cb += ET) {
+        const int ce = cb + ET < e1 ? cb + ET : e1;
+        // phase 1, four entry passes at a time: unconditional loads at clamped indices, so that the four
+        // column/value loads and then the four gathers are issued back to back
+#pragma unroll
+        for (int g = 0; g < PASSES; g += GP) {
+            if (cb + g * RPW >= ce) break;               // uniform
+            int c[GP];
+            float v[GP];
+#pragma unroll
+            for (int k = 0; k < GP; ++k) {
+                const int e = cb + slot + (g + k) * RPW;
+                const int ec = e < ce ? e : ce - 1;
+                c[k] = col[ec];
+                v[k] = val[ec];
+            }
+            float4 xv[GP];
+#pragma unroll
+            for (int k = 0; k < GP; ++k) {
+                const float *xr = x + (size_t)c[k] * d;
+                if (ALIGNED) {
+                    xv[k] = *reinterpret_cast<const float4 *>(xr + 4 * sub);
+                } else {
+                    float t[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int b = 4 * sub + j;
+                        const float w = xr[b < d ? b : d - 1];
+                        t[j] = b < d ? w : 0.f;
+                    }
+                    xv[k] = make_float4(t[0], t[1], t[2], t[3]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < GP; ++k) {
+                const int e = cb + slot + (g + k) * RPW;
+                if (e < ce) {
+                    s_x[(e - cb) * VEC + sub] = xv[k];
+                    if (sub == 0) s_val[e - cb] = v[k];
+                }
+            }
+        }
+        __syncthreads();
+        // phase 2
+        const int lo = beg > cb ? beg : cb;
+        const int hi = end < ce ? end : ce;
+        const bool is_long = hi - lo > kLongRow;
+        if (!is_long) {
+            for (int e = lo; e < hi; ++e) {
+                const float w = s_val[e - cb];
+                const float4 t = s_x[(e - cb) * VEC + sub];
+                acc.x = fmaf(w, t.x, acc.x);
+                acc.y = fmaf(w, t.y, acc.y);
+                acc.z = fmaf(w, t.z, acc.z);
+                acc.w = fmaf(w, t.w, acc.w);
+            }
+        } else if (sub == 0) {
+            s_long[atomicAdd(&s_nlong, 1)] = slot;       // LDS counter; the order of the list does not matter
+        }
+        __syncthreads();
+        const int n_long = s_nlong;
+        for (int k = 0; k < n_long; ++k) {               // uniform over the workgroup
+            const int rs = s_long[k];
+            const int lo_k = s_crow[rs] > cb ? s_crow[rs] : cb;
+            const int hi_k = s_crow[rs + 1] < ce ? s_crow[rs + 1] : ce;
+            float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int e = lo_k + slot; e < hi_k; e += RPW) {
+                const float w = s_val[e - cb];
+                const float4 t = s_x[(e - cb) * VEC + sub];
+                part.x = fmaf(w, t.x, part.x);
+                part.y = fmaf(w, t.y, part.y);
+                part.z = fmaf(w, t.z, part.z);
+                part.w = fmaf(w, t.w, part.w);
+            }
+            s_red[tid] = part;
+            __syncthreads();
+            for (int off = RPW / 2; off >= 1; off >>= 1) {
+                if (slot < off) {
+                    const float4 o = s_red[(slot + off) * VEC + sub];
+                    float4 m = s_red[tid];
+                    m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+                    s_red[tid] = m;
+                }
+                __syncthreads();
+            }
+            if (slot == rs) {
+                const float4 t = s_red[sub];
+                acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) s_nlong = 0;
+        __syncthreads();
+    }
+
+    if (!has_row) return;
+    float *yr = y + (size_t)(r0 + slot) * d;
+    const int b = 4 * sub;
+    if (ALIGNED) {
+        float4 *yp = reinterpret_cast<float4 *>(yr + b);
+        if (accumulate) {
+            const float4 o = *yp;
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+        *yp = acc;
+    } else {
+        const float a[4] = {acc.x, acc.y, acc.z, acc.w};
+        for (int k = 0; k < 4; ++k)
+            if (b + k < d) yr[b + k] = accumulate ? yr[b + k] + a[k] : a[k];
+    }
+}
+
+template <int VEC>
+int launch_tile(const int32_t *crow, const int32_t *col, const float *val, int64_t n, int64_t d, const float *x,
+                float *y, int accumulate, hipStream_t stream) {
+    const bool aligned = (d == 4 * VEC) && ((((uintptr_t)x | (uintptr_t)y) & 15u) == 0);
+    const dim3 grid((unsigned)rwk_ceil_div(n, kBlock / VEC));
+    if (aligned)
+        hipLaunchKernelGGL((spmm_tile_kernel<VEC, true>), grid, dim3(kBlock), 0, stream, crow, col, val, (int)n, (int)d,
+                           x, y, accumulate);
+    else
+        hipLaunchKernelGGL((spmm_tile_kernel<VEC, false>), grid, dim3(kBlock), 0, stream, crow, col, val, (int)n,
+                           (int)d, x, y, accumulate);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
 template <int VEC>
 int launch(const int32_t *crow, const int32_t *col, const float *val, int64_t n, int64_t d, const float *x,
            float *y, int accumulate, int r_lanes, const int32_t *long_rows, int64_t n_long,
@@ -124,10 +297,17 @@ extern "C" int rwk_spmm_csr(const int32_t *crow, const int32_t *col, const float
     RWK_REQUIRE_PTR(y);
     if (n <= 0 || n >= 0x7FFFFFFFll || d <= 0 || n_long < 0 || n_long > n) return RWK_E_SIZE;
     if (d > 64) return RWK_E_UNSUPPORTED;
-    if (row_lanes < 1 || row_lanes > 64 || (row_lanes & (row_lanes - 1))) return RWK_E_SIZE;
+    if (row_lanes < 0 || row_lanes > 64 || (row_lanes & (row_lanes - 1))) return RWK_E_SIZE;
     if (n * 64 >= (int64_t)0x7FFFFFFF * kBlock) return RWK_E_SIZE;
     hipStream_t stream = (hipStream_t)stream_;
     const int vec = (int)((d + 3) / 4);
+    if (row_lanes == 0) {                               // sparse rows: the tile kernel (hubs handled inside)
+        if (vec == 1) return launch_tile<1>(crow, col, val, n, d, x, y, accumulate, stream);
+        if (vec == 2) return launch_tile<2>(crow, col, val, n, d, x, y, accumulate, stream);
+        if (vec <= 4) return launch_tile<4>(crow, col, val, n, d, x, y, accumulate, stream);
+        if (vec <= 8) return launch_tile<8>(crow, col, val, n, d, x, y, accumulate, stream);
+        return launch_tile<16>(crow, col, val, n, d, x, y, accumulate, stream);
+    }
     if (vec == 1) return launch<1>(crow, col, val, n, d, x, y, accumulate, row_lanes, long_rows, n_long, long_threshold, stream);
     if (vec == 2) return launch<2>(crow, col, val, n, d, x, y, accumulate, row_lanes, long_rows, n_long, long_threshold, stream);
     if (vec <= 4) return launch<4>(crow, col, val, n, d, x, y, accumulate, row_lanes, long_rows, n_long, long_threshold, stream);

@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["GraphStructure", "get_structure", "clear_structure_cache"]
+__all__ = ["GraphStructure", "get_structure", "clear_structure_cache", "spmm_schedule", "use_tile_kernel"]
 
 
 class _Csr:
@@ -49,6 +49,19 @@ def spmm_schedule(n: int, nnz: int, max_degree: int):
     row_lanes = 1 if mean < 8 else min(16, _pow2_floor(int(mean // 4)))
     long_threshold = 128 * row_lanes
     return row_lanes, (long_threshold if max_degree > long_threshold else 0)
+
+
+def use_tile_kernel(n: int, nnz: int, max_degree: int, d: int) -> bool:
+    """Sparse rows go to the tile kernel (``row_lanes = 0``): entry-parallel loads through LDS, hubs summed by
+    the whole workgroup.  Dense matrices (mean degree >= 32) and wide operands on very sparse rows (fewer than
+    48 stored entries per workgroup of 256/ceil(d/4) rows, and no hubs) stay on the packed kernel."""
+    mean = nnz / max(n, 1)
+    if mean >= 32:
+        return False
+    vec = 1
+    while vec * 4 < d:
+        vec *= 2
+    return max_degree > 128 or mean * (256 // vec) >= 48
 
 
 class GraphStructure:
@@ -183,13 +196,17 @@ class GraphStructure:
             csr.long_rows = torch.nonzero(deg > csr.long_threshold).flatten().to(torch.int32)
 
     # ------------------------------------------------------------------------------------
-    def spmm(self, x: torch.Tensor, y: torch.Tensor, transpose: bool = False, accumulate: bool = False):
-        """y = A x (or A^T x), optionally accumulated into y.  x, y: contiguous (N, D) float32."""
+    def spmm(self, x: torch.Tensor, y: torch.Tensor, transpose: bool = False, accumulate: bool = False,
+             kernel: Optional[str] = None):
+        """y = A x (or A^T x), optionally accumulated into y.  x, y: contiguous (N, D) float32.
+        ``kernel``: "tile" or "packed" to force a schedule (tests); default: the degree-histogram rule."""
         lib = _lib.load()
         csr = self.csr_t if transpose else self.csr
-        n_long = 0 if csr.long_rows is None else csr.long_rows.numel()
+        tile = use_tile_kernel(self.n, self.nnz, csr.max_degree, x.shape[1]) if kernel is None else kernel == "tile"
+        n_long = 0 if (tile or csr.long_rows is None) else csr.long_rows.numel()
         _lib.check(lib.rwk_spmm_csr(csr.crow.data_ptr(), _lib.ptr(csr.col), _lib.ptr(csr.val), self.n,
-                                    x.shape[1], x.data_ptr(), y.data_ptr(), int(accumulate), csr.row_lanes,
+                                    x.shape[1], x.data_ptr(), y.data_ptr(), int(accumulate),
+                                    0 if tile else csr.row_lanes,
                                     _lib.ptr(csr.long_rows), n_long, csr.long_threshold,
                                     _lib.current_stream(self.device)), "rwk_spmm_csr")
 

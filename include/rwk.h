@@ -87,8 +87,14 @@ int rwk_segments_build(const int64_t *ids_sorted, int64_t n, int64_t n_graphs, i
  * ------------------------------------------------------------------------------------- */
 
 /* x, y: (n, d) row-major, d <= 64.  accumulate != 0: y += A x.
+ * The caller picks the schedule from the degree histogram:
+ * row_lanes = 0: tile kernel for sparse rows (mean degree up to a few tens).  A workgroup owns
+ * 256/ceil(d/4) consecutive rows; their stored entries are read entry-parallel (coalesced
+ * columns and values, all x-row gathers of a pass in flight together) into LDS and then added
+ * row by row in stored order; rows with more than 64 entries (hubs) are summed by the whole
+ * workgroup in a fixed tree order.  long_rows / n_long / long_threshold are ignored.
  * row_lanes (power of two, 1..64): lanes that share the stored entries of one row in the
- * packed pass; the caller picks it from the degree histogram (1 for degree <= ~8).
+ * packed pass (dense rows).
  * When long_rows != NULL and n_long > 0, rows with more than `long_threshold` entries are
  * skipped by the packed pass and must be listed in long_rows (n_long of them, ascending):
  * each is then summed by a whole wavefront.  Summation order is fixed in both passes. */

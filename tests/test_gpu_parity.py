@@ -219,12 +219,14 @@ def test_dropout_mask_replay(name, p, dev):
 
 
 def test_spmm_directed_and_long_rows(dev):
-    """A x and A^T x on a directed, weighted graph with a few hub rows (exercises the wavefront-per-row pass)."""
+    """A x and A^T x on a directed, weighted graph with a few hub rows, through both SpMM schedules: the
+    packed kernel (wavefront-per-row pass for the hubs) and the tile kernel (hubs summed by the workgroup,
+    one of them spanning several LDS tiles; empty rows; a last workgroup with fewer rows)."""
     from gnn_amd import GraphStructure
     rng = np.random.default_rng(5)
-    n = 3000
-    rows = [rng.integers(0, n, size=6000), np.full(900, 7), np.full(400, 1234), rng.integers(0, n, 300)]
-    cols = [rng.integers(0, n, size=6000), rng.choice(n, 900, replace=False), rng.choice(n, 400, replace=False),
+    n = 6001
+    rows = [rng.integers(0, n, size=12000), np.full(5000, 7), np.full(400, 1234), rng.integers(0, n, 300)]
+    cols = [rng.integers(0, n, size=12000), rng.choice(n, 5000, replace=False), rng.choice(n, 400, replace=False),
             np.full(300, 99)]
     r = np.concatenate(rows)
     cidx = np.concatenate(cols)
@@ -238,17 +240,22 @@ def test_spmm_directed_and_long_rows(dev):
     assert st.csr.long_rows is not None and st.csr.long_rows.numel() >= 2
     crow, col, val = O.coo_to_csr(np.vstack([r, cidx]), v, n)
     t_crow, t_col, t_val = O.csr_transpose(crow, col, val, n)
-    for d in (1, 4, 6, 16, 32, 64):
+    for d in (1, 3, 4, 6, 8, 16, 20, 32, 64):
         x = rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
         xd = torch.from_numpy(x).to(dev)
-        y = torch.empty_like(xd)
-        st.spmm(xd, y)
-        assert rel_err(y.cpu().numpy(), O.csr_matmul(crow, col, val, x.astype(np.float64))) < TOL
+        ax = O.csr_matmul(crow, col, val, x.astype(np.float64))
+        atx = O.csr_matmul(t_crow, t_col, t_val, x.astype(np.float64))
         y0 = torch.from_numpy(rng.uniform(-1, 1, size=(n, d)).astype(np.float32)).to(dev)
-        y1 = y0.clone()
-        st.spmm(xd, y1, transpose=True, accumulate=True)
-        want = y0.cpu().numpy().astype(np.float64) + O.csr_matmul(t_crow, t_col, t_val, x.astype(np.float64))
-        assert rel_err(y1.cpu().numpy(), want) < TOL
+        for kernel in ("packed", "tile", None):
+            y = torch.full_like(xd, float("nan"))
+            st.spmm(xd, y, kernel=kernel)
+            assert rel_err(y.cpu().numpy(), ax) < TOL, (d, kernel)
+            y1 = y0.clone()
+            st.spmm(xd, y1, transpose=True, accumulate=True, kernel=kernel)
+            assert rel_err(y1.cpu().numpy(), y0.cpu().numpy().astype(np.float64) + atx) < TOL, (d, kernel)
+            y2 = torch.full_like(xd, float("nan"))
+            st.spmm(xd, y2, kernel=kernel)
+            assert torch.equal(y, y2), "SpMM must be bitwise reproducible"
 
 
 def test_error_behaviour(dev):

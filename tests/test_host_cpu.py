@@ -97,6 +97,12 @@ def test_spmm_schedule_rule():
     assert spmm_schedule(3000, 7000, 900) == (1, 128)
     lanes, thr = spmm_schedule(1000, 64000, 80)
     assert lanes == 16 and thr == 0
+    from gnn_amd.structure import use_tile_kernel
+    assert use_tile_kernel(307842, 1132004, 12, 4)            # protein-like batch, hidden_dim 4
+    assert use_tile_kernel(190013, 622914, 1900, 64)          # hubs: always
+    assert not use_tile_kernel(102962, 217050, 8, 64)         # 35 entries per 16-row workgroup
+    assert use_tile_kernel(102962, 217050, 8, 16)
+    assert not use_tile_kernel(1000, 64000, 80, 4)            # dense rows
 
 
 def test_stream_length_rule():
