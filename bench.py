@@ -104,6 +104,10 @@ class Trainer:
                 self.step_eager()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        # Drop the warm-up's autograd graph before capturing: its AccumulateGrad nodes are bound to the warm-up
+        # stream, and reusing them would fork the captured backward over two streams (torch warns about it; the
+        # forked replay was seen to feed stale gradients to the random-walk layer).
+        self.loss = None
         self.g_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_fb):
             self.fwd_bwd()

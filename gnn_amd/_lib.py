@@ -38,6 +38,14 @@ SIGNATURES = {
     "rwk_fused_backward_workspace": (_I64, [_I64, _I64, _I64, _I64, _I64]),
     "rwk_fused_path": (c_int, [_I64, _I64, _I64, _I64]),
     "rwk_fused_stream_len": (_I64, [_I64, _I64, _I64, _I64, _I64, c_int]),
+    "rwk_head_supported": (c_int, [_I64, _I64, _I64, _I64]),
+    "rwk_head_n_blocks": (_I64, [_I64]),
+    "rwk_head_stats_size": (_I64, [_I64, _I64]),
+    "rwk_head_grad_size": (_I64, [_I64, _I64, _I64]),
+    "rwk_head_forward": (c_int, [_P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, c_float, c_float, c_int, _P,
+                                 _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "rwk_head_backward": (c_int, [_P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_float,
+                                  _P, _P, _P, _P, _P]),
     "rwk_project_forward": (c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
     "rwk_project_backward_blocks": (_I64, [_I64, _I64]),
     "rwk_project_backward": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P]),

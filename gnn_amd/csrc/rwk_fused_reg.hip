@@ -165,7 +165,6 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
         load_tile<LT>(tile, x, gid, perm, start + base + lane_h, end, has_stream, d, step_stride);
         __syncthreads();
         const int jmax = stream_len - base < hp ? stream_len - base : hp;
-#pragma unroll 2
         for (int j = 0; j < jmax; ++j) {
             const int node = tile.node[group0 + j];
             const int g = tile.gid[group0 + j];
@@ -259,7 +258,6 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
         const int my_node = tile.node[tid];
         // every lane of the wavefront runs all hp iterations: the DPP butterfly needs them all
         const int jmax = stream_len - base < hp ? stream_len - base : hp;
-#pragma unroll 2
         for (int j = 0; j < jmax; ++j) {
             const int node = tile.node[group0 + j];
             const int g = tile.gid[group0 + j];

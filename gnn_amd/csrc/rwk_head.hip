@@ -1,0 +1,537 @@
+// Classifier head of RW_NN in four launches instead of ~35:
+//   BatchNorm1d(C) -> Linear(C, P) -> ReLU -> Dropout(p) -> Linear(P, NC) -> log_softmax
+// (rwgnn2/model.py:68-72 and their autograd backward).  G rows (graphs) of C = max_step * hidden_graphs
+// kernel features; everything is tiny next to the random-walk layer, so the kernels are plain vector-ALU code
+// whose only aim is to be few launches, deterministic (fixed summation orders, no atomics) and exact fp32.
+//
+//   forward, training:  head_stats_kernel   per-block (count, mean, M2) of each column, merged with Chan's formula
+//                       head_apply_kernel   normalise, both linear layers, dropout, log-softmax; running stats
+//   backward:           head_bwd_tile_kernel  d(logits), d(pre-activations), dY; per-block partial parameter sums
+//                       head_bwd_finish_kernel  parameter gradients, batch-norm input gradient
+//
+// Rows are processed in tiles of kRows; a block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...
+#include "rwk_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kRows = 32;
+constexpr int kMaxBlocks = 256;
+constexpr int kMaxC = 256, kMaxNC = 32, kMaxPC = 4096;
+constexpr uint32_t kHeadCall = 0xFFFFFFFFu;       // Philox counter word no other mask of the model uses
+
+__host__ __device__ inline int head_blocks(long long g) {
+    const long long t = (g + kRows - 1) / kRows;
+    return (int)(t < kMaxBlocks ? t : kMaxBlocks);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// batch statistics: partials[b] = {count, mean[C], M2[C]} over the rows of block b's tiles
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+head_stats_kernel(const float *__restrict__ k, long long g, int c, float *__restrict__ partials,
+                  unsigned long long *rng_state, unsigned long long *rng_used) {
+    __shared__ float red[kBlock];
+    __shared__ float s_mean[kMaxC];
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0 && rng_state != nullptr && rng_used != nullptr) {
+        const unsigned long long seed = rng_state[0], off = rng_state[1];
+        rng_used[0] = seed;
+        rng_used[1] = off;
+        rng_state[1] = off + 1ull;
+    }
+    const int tpc = kBlock / c;                    // row lanes per column (c <= 256)
+    const int col = tid % c, rl = tid / c;
+    const bool lane_ok = rl < tpc;
+    const long long n_tiles = (g + kRows - 1) / kRows;
+    // pass 1: column sums
+    float sum = 0.f;
+    long long count = 0;
+    for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const long long r0 = t * kRows;
+        const int nr = (int)(g - r0 < kRows ? g - r0 : kRows);
+        count += nr;
+        if (lane_ok)
+            for (int r = rl; r < nr; r += tpc) sum += k[(r0 + r) * c + col];
+    }
+    red[tid] = lane_ok ? sum : 0.f;
+    __syncthreads();
+    if (tid < c) {
+        float s = 0.f;
+        for (int q = 0; q < tpc; ++q) s += red[q * c + tid];
+        s_mean[tid] = count > 0 ? s / (float)count : 0.f;
+    }
+    __syncthreads();
+    // pass 2: sum of squared deviations from the block mean
+    const float mu = s_mean[col];
+    float m2 = 0.f;
+    for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const long long r0 = t * kRows;
+        const int nr = (int)(g - r0 < kRows ? g - r0 : kRows);
+        if (lane_ok)
+            for (int r = rl; r < nr; r += tpc) {
+                const float dv = k[(r0 + r) * c + col] - mu;
+                m2 = fmaf(dv, dv, m2);
+            }
+    }
+    red[tid] = lane_ok ? m2 : 0.f;
+    __syncthreads();
+    float *out = partials + (size_t)blockIdx.x * (1 + 2 * c);
+    if (tid == 0) out[0] = (float)count;
+    if (tid < c) {
+        float s = 0.f;
+        for (int q = 0; q < tpc; ++q) s += red[q * c + tid];
+        out[1 + tid] = s_mean[tid];
+        out[1 + c + tid] = s;
+    }
+}
+
+// (n, mean, M2) <- merge of (n, mean, M2) and (nb, mb, qb)   (Chan et al.)
+__device__ inline void chan_merge(float &n, float &mean, float &m2, float nb, float mb, float qb) {
+    if (nb <= 0.f) return;
+    const float delta = mb - mean;
+    const float nn = n + nb;
+    mean += delta * (nb / nn);
+    m2 += qb + delta * delta * (n * nb / nn);
+    n = nn;
+}
+
+// Batch statistics of one column from the per-block partials, computed by 8 cooperating lanes (lane8 = 0..7 of
+// an aligned group): lane l merges blocks l, l+8, ... in order, then the eight results are merged pairwise, the
+// lower lane's value always on the left, so that every lane (and every workgroup) ends with the same bits.
+__device__ inline float merge_stats8(const float *__restrict__ partials, int n_blocks, int c, int col, int lane8,
+                                     float *var) {
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int b = lane8; b < n_blocks; b += 8) {
+        const float *p = partials + (size_t)b * (1 + 2 * c);
+        chan_merge(n, mean, m2, p[0], p[1 + col], p[1 + c + col]);
+    }
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+        const float on = __shfl_xor(n, off, 64), om = __shfl_xor(mean, off, 64), oq = __shfl_xor(m2, off, 64);
+        const bool upper = (lane8 & off) != 0;
+        float ln = upper ? on : n, lm = upper ? om : mean, lq = upper ? oq : m2;
+        chan_merge(ln, lm, lq, upper ? n : on, upper ? mean : om, upper ? m2 : oq);
+        n = ln; mean = lm; m2 = lq;
+    }
+    *var = n > 0.f ? m2 / n : 0.f;
+    return mean;
+}
+
+struct HeadDims {
+    long long g;
+    int c, p, nc;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+head_apply_kernel(const float *__restrict__ k, HeadDims dm, const float *__restrict__ bn_w,
+                  const float *__restrict__ bn_b, float *running_mean, float *running_var,
+                  long long *num_batches_tracked, float momentum, float eps, int training,
+                  const float *__restrict__ partials, int n_partials, const float *__restrict__ w1,
+                  const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2,
+                  float drop_p, const unsigned long long *__restrict__ rng, float *__restrict__ mean_out,
+                  float *__restrict__ invstd_out, float *__restrict__ h1d_out, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int c = dm.c, p = dm.p, nc = dm.nc;
+    const int cs = c + 1, ps = p + 1;
+    float *s_w1 = lds;                       // [p][cs]
+    float *s_w2 = s_w1 + p * cs;             // [nc][ps]
+    float *s_b1 = s_w2 + nc * ps;            // [p]
+    float *s_b2 = s_b1 + p;                  // [nc]
+    float *s_scale = s_b2 + nc;              // [c]
+    float *s_shift = s_scale + c;            // [c]
+    float *s_y = s_shift + c;                // [kRows][cs]
+    float *s_h = s_y + kRows * cs;           // [kRows][ps]
+    float *s_o = s_h + kRows * ps;           // [kRows][nc]
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < p * c; i += kBlock) s_w1[(i / c) * cs + i % c] = w1[i];
+    for (int i = tid; i < nc * p; i += kBlock) s_w2[(i / p) * ps + i % p] = w2[i];
+    for (int i = tid; i < p; i += kBlock) s_b1[i] = b1[i];
+    for (int i = tid; i < nc; i += kBlock) s_b2[i] = b2[i];
+    const int lane8 = tid & 7;
+    for (int c0 = 0; c0 < c; c0 += kBlock / 8) {             // uniform trip count: the shuffles need all lanes
+        const int col_raw = c0 + (tid >> 3);
+        const int col = col_raw < c ? col_raw : c - 1;
+        float mean, var;
+        if (training) {
+            mean = merge_stats8(partials, n_partials, c, col, lane8, &var);
+        } else {
+            mean = running_mean[col];
+            var = running_var[col];
+        }
+        if (lane8 != 0 || col_raw >= c) continue;
+        if (training && blockIdx.x == 0) {
+            // running estimates as torch.nn.BatchNorm1d keeps them: unbiased variance, momentum update
+            const float unbiased = dm.g > 1 ? var * ((float)dm.g / (float)(dm.g - 1)) : var;
+            running_mean[col] = (1.f - momentum) * running_mean[col] + momentum * mean;
+            running_var[col] = (1.f - momentum) * running_var[col] + momentum * unbiased;
+            if (col == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
+        }
+        const float invstd = 1.f / sqrtf(var + eps);
+        if (blockIdx.x == 0 && mean_out != nullptr) {
+            mean_out[col] = mean;
+            invstd_out[col] = invstd;
+        }
+        const float sc = bn_w[col] * invstd;
+        s_scale[col] = sc;
+        s_shift[col] = bn_b[col] - mean * sc;
+    }
+    __syncthreads();
+
+    const bool drop = training && drop_p > 0.f;
+    uint32_t seed_lo = 0, key_hi = 0, off_lo = 0, keep_thr = 0xFFFFFFFFu;
+    float keep_scale = 1.f;
+    if (drop) {
+        const unsigned long long seed = rng[0], off = rng[1];
+        seed_lo = (uint32_t)seed;
+        key_hi = (uint32_t)(seed >> 32) ^ (uint32_t)(off >> 32);
+        off_lo = (uint32_t)off;
+        const double q = 1.0 - (double)drop_p;
+        const double thr = q * 4294967296.0;
+        keep_thr = thr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)thr;
+        keep_scale = 1.f / (1.f - drop_p);
+    }
+
+    const long long n_tiles = (dm.g + kRows - 1) / kRows;
+    for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const long long r0 = t * kRows;
+        const int nr = (int)(dm.g - r0 < kRows ? dm.g - r0 : kRows);
+        for (int i = tid; i < nr * c; i += kBlock) {
+            const int r = i / c, col = i % c;
+            s_y[r * cs + col] = fmaf(k[(r0 + r) * c + col], s_scale[col], s_shift[col]);
+        }
+        __syncthreads();
+        for (int i = tid; i < nr * p; i += kBlock) {
+            const int r = i / p, j = i % p;
+            float acc = s_b1[j];
+            const float *yr = s_y + r * cs, *wr = s_w1 + j * cs;
+#pragma unroll 8
+            for (int col = 0; col < c; ++col) acc = fmaf(yr[col], wr[col], acc);
+            acc = acc > 0.f ? acc : 0.f;
+            if (drop) {
+                const RwkPhilox4 rr = rwk_philox4x32_10((uint32_t)(r0 + r), (uint32_t)(j >> 2), kHeadCall, off_lo,
+                                                        seed_lo, key_hi);
+                const uint32_t wv[4] = {rr.x, rr.y, rr.z, rr.w};
+                acc = wv[j & 3] < keep_thr ? acc * keep_scale : 0.f;
+            }
+            s_h[r * ps + j] = acc;
+            if (h1d_out != nullptr) h1d_out[(r0 + r) * p + j] = acc;
+        }
+        __syncthreads();
+        for (int i = tid; i < nr * nc; i += kBlock) {
+            const int r = i / nc, q = i % nc;
+            float acc = s_b2[q];
+            const float *hr = s_h + r * ps, *wr = s_w2 + q * ps;
+#pragma unroll 8
+            for (int j = 0; j < p; ++j) acc = fmaf(hr[j], wr[j], acc);
+            s_o[r * nc + q] = acc;
+        }
+        __syncthreads();
+        if (tid < nr) {
+            const float *o = s_o + tid * nc;
+            float mx = o[0];
+            for (int q = 1; q < nc; ++q) mx = fmaxf(mx, o[q]);
+            float se = 0.f;
+            for (int q = 0; q < nc; ++q) se += expf(o[q] - mx);
+            const float lse = mx + logf(se);
+            for (int q = 0; q < nc; ++q) out[(r0 + tid) * nc + q] = o[q] - lse;
+        }
+        __syncthreads();
+    }
+}
+
+// parameter-gradient vector of one block: [dW2 (nc*p) | db2 (nc) | dW1 (p*c) | db1 (p) | dgamma (c) | dbeta (c)]
+__host__ __device__ inline int head_nv(int c, int p, int nc) { return nc * p + nc + p * c + p + 2 * c; }
+
+// ---------------------------------------------------------------------------------------------------
+// backward, first launch
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+head_bwd_tile_kernel(const float *__restrict__ k, HeadDims dm, const float *__restrict__ bn_w,
+                     const float *__restrict__ bn_b, const float *__restrict__ mean, const float *__restrict__ invstd,
+                     const float *__restrict__ w1, const float *__restrict__ w2, const float *__restrict__ h1d,
+                     const float *__restrict__ out, const float *__restrict__ d_out, float keep_scale,
+                     float *__restrict__ dy, float *__restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int c = dm.c, p = dm.p, nc = dm.nc;
+    const int cs = c + 1, ps = p + 1;
+    const int nv = head_nv(c, p, nc);
+    float *s_w1 = lds;                       // [p][cs]
+    float *s_w2 = s_w1 + p * cs;             // [nc][ps]
+    float *s_xh = s_w2 + nc * ps;            // [kRows][cs]  normalised input
+    float *s_dy = s_xh + kRows * cs;         // [kRows][cs]
+    float *s_h = s_dy + kRows * cs;          // [kRows][ps]  hidden activations after dropout
+    float *s_dp = s_h + kRows * ps;          // [kRows][ps]  gradient of the first layer's pre-activation
+    float *s_dl = s_dp + kRows * ps;         // [kRows][nc]  gradient of the logits
+    float *s_g = s_dl + kRows * nc;          // [nv]
+    float *s_ga = s_g + nv;                  // [c] batch-norm weight
+    float *s_be = s_ga + c;                  // [c] batch-norm bias
+    float *s_mu = s_be + c;                  // [c]
+    float *s_is = s_mu + c;                  // [c]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < p * c; i += kBlock) s_w1[(i / c) * cs + i % c] = w1[i];
+    for (int i = tid; i < nc * p; i += kBlock) s_w2[(i / p) * ps + i % p] = w2[i];
+    for (int i = tid; i < nv; i += kBlock) s_g[i] = 0.f;
+    for (int i = tid; i < c; i += kBlock) {
+        s_ga[i] = bn_w[i];
+        s_be[i] = bn_b[i];
+        s_mu[i] = mean[i];
+        s_is[i] = invstd[i];
+    }
+    __syncthreads();
+
+    const int o_b2 = nc * p, o_w1 = o_b2 + nc, o_b1 = o_w1 + p * c, o_ga = o_b1 + p, o_be = o_ga + c;
+    const long long n_tiles = (dm.g + kRows - 1) / kRows;
+    for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const long long r0 = t * kRows;
+        const int nr = (int)(dm.g - r0 < kRows ? dm.g - r0 : kRows);
+        for (int i = tid; i < nr * c; i += kBlock) {
+            const int r = i / c, col = i % c;
+            s_xh[r * cs + col] = (k[(r0 + r) * c + col] - s_mu[col]) * s_is[col];
+        }
+        for (int i = tid; i < nr * p; i += kBlock) s_h[(i / p) * ps + i % p] = h1d[r0 * p + i];
+        if (tid < nr) {                                  // log-softmax backward, one row per thread
+            const float *go = d_out + (r0 + tid) * nc, *lo = out + (r0 + tid) * nc;
+            float s = 0.f;
+            for (int q = 0; q < nc; ++q) s += go[q];
+            for (int q = 0; q < nc; ++q) s_dl[tid * nc + q] = go[q] - expf(lo[q]) * s;
+        }
+        __syncthreads();
+        for (int i = tid; i < nr * p; i += kBlock) {
+            const int r = i / p, j = i % p;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int q = 0; q < nc; ++q) acc = fmaf(s_dl[r * nc + q], s_w2[q * ps + j], acc);
+            s_dp[r * ps + j] = s_h[r * ps + j] > 0.f ? acc * keep_scale : 0.f;
+        }
+        __syncthreads();
+        for (int i = tid; i < nr * c; i += kBlock) {
+            const int r = i / c, col = i % c;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < p; ++j) acc = fmaf(s_dp[r * ps + j], s_w1[j * cs + col], acc);
+            s_dy[r * cs + col] = acc;
+            dy[(r0 + r) * c + col] = acc;
+        }
+        __syncthreads();
+        // every thread owns the gradient elements e = tid, tid + 256, ...: rows are added in row order
+        for (int e = tid; e < nv; e += kBlock) {
+            float acc = 0.f;
+            if (e < o_b2) {
+                const int q = e / p, j = e % p;
+#pragma unroll 8
+                for (int r = 0; r < nr; ++r) acc = fmaf(s_dl[r * nc + q], s_h[r * ps + j], acc);
+            } else if (e < o_w1) {
+                const int q = e - o_b2;
+#pragma unroll 8
+                for (int r = 0; r < nr; ++r) acc += s_dl[r * nc + q];
+            } else if (e < o_b1) {
+                const int j = (e - o_w1) / c, col = (e - o_w1) % c;
+                const float ga = s_ga[col], be = s_be[col];
+#pragma unroll 8
+                for (int r = 0; r < nr; ++r) acc = fmaf(s_dp[r * ps + j], fmaf(s_xh[r * cs + col], ga, be), acc);
+            } else if (e < o_ga) {
+                const int j = e - o_b1;
+#pragma unroll 8
+                for (int r = 0; r < nr; ++r) acc += s_dp[r * ps + j];
+            } else if (e < o_be) {
+                const int col = e - o_ga;
+#pragma unroll 8
+                for (int r = 0; r < nr; ++r) acc = fmaf(s_dy[r * cs + col], s_xh[r * cs + col], acc);
+            } else {
+                const int col = e - o_be;
+#pragma unroll 8
+                for (int r = 0; r < nr; ++r) acc += s_dy[r * cs + col];
+            }
+            s_g[e] += acc;
+        }
+        __syncthreads();
+    }
+    float *dst = partials + (size_t)blockIdx.x * nv;
+    for (int e = tid; e < nv; e += kBlock) dst[e] = s_g[e];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward, second launch: parameter gradients (block partials added in block order) and dK
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+head_bwd_finish_kernel(const float *__restrict__ k, HeadDims dm, const float *__restrict__ bn_w,
+                       const float *__restrict__ mean, const float *__restrict__ invstd,
+                       const float *__restrict__ dy, const float *__restrict__ partials, int n_partials, int training,
+                       float *__restrict__ grads, float *__restrict__ d_k) {
+    __shared__ float s_dga[kMaxC], s_dbe[kMaxC];
+    const int c = dm.c, p = dm.p, nc = dm.nc;
+    const int nv = head_nv(c, p, nc);
+    const int tid = threadIdx.x;
+    const int o_ga = nc * p + nc + p * c + p;
+    // this block's slice of the parameter gradients: eight lanes share the block partials of one element
+    // (independent loads in flight) and are then added in a fixed butterfly order
+    const int lane8 = tid & 7, grp = tid >> 3;
+    const int per = (nv + gridDim.x - 1) / gridDim.x;
+    const int e_lo = blockIdx.x * per, e_hi = e_lo + per < nv ? e_lo + per : nv;
+    for (int e0 = e_lo; e0 < e_hi; e0 += kBlock / 8) {      // uniform trip count: the shuffles need all lanes
+        const int e = e0 + grp;
+        const int ec = e < e_hi ? e : e_hi - 1;
+        float acc = 0.f;
+        for (int b = lane8; b < n_partials; b += 8) acc += partials[(size_t)b * nv + ec];
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        if (lane8 == 0 && e < e_hi) grads[e] = acc;
+    }
+    if (d_k == nullptr) return;
+    for (int c0 = 0; c0 < 2 * c; c0 += kBlock / 8) {
+        const int q = c0 + grp;                              // q < c: dgamma column, else dbeta column
+        const int qc = q < 2 * c ? q : 2 * c - 1;
+        float acc = 0.f;
+        for (int b = lane8; b < n_partials; b += 8) acc += partials[(size_t)b * nv + o_ga + qc];
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        if (lane8 == 0 && q < 2 * c) {
+            if (q < c) s_dga[q] = acc; else s_dbe[q - c] = acc;
+        }
+    }
+    __syncthreads();
+    const float inv_g = 1.f / (float)dm.g;
+    const long long n_tiles = (dm.g + kRows - 1) / kRows;
+    for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const long long r0 = t * kRows;
+        const int nr = (int)(dm.g - r0 < kRows ? dm.g - r0 : kRows);
+        for (int i = tid; i < nr * c; i += kBlock) {
+            const int col = i % c;
+            const long long at = r0 * c + i;
+            const float sc = bn_w[col] * invstd[col];
+            float v = dy[at];
+            if (training) {
+                const float xh = (k[at] - mean[col]) * invstd[col];
+                v = v - s_dbe[col] * inv_g - xh * s_dga[col] * inv_g;
+            }
+            d_k[at] = v * sc;
+        }
+    }
+}
+
+size_t fwd_lds(int c, int p, int nc) {
+    return sizeof(float) * ((size_t)p * (c + 1) + (size_t)nc * (p + 1) + p + nc + 2 * c + (size_t)kRows * (c + 1) +
+                            (size_t)kRows * (p + 1) + (size_t)kRows * nc);
+}
+size_t bwd_lds(int c, int p, int nc) {
+    return sizeof(float) * ((size_t)p * (c + 1) + (size_t)nc * (p + 1) + 2 * (size_t)kRows * (c + 1) +
+                            2 * (size_t)kRows * (p + 1) + (size_t)kRows * nc + head_nv(c, p, nc) + 4 * (size_t)c);
+}
+
+bool dims_ok(int64_t g, int64_t c, int64_t p, int64_t nc) {
+    return g >= 1 && c >= 1 && c <= kMaxC && p >= 1 && nc >= 1 && nc <= kMaxNC && p * c <= kMaxPC &&
+           g < (int64_t)1 << 40;
+}
+
+template <typename K>
+int allow_lds(K kern, size_t lds) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    return RWK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rwk_head_supported(int64_t g, int64_t c, int64_t p, int64_t nc) {
+    return dims_ok(g, c, p, nc) && bwd_lds((int)c, (int)p, (int)nc) <= 150 * 1024 ? 1 : 0;
+}
+
+int64_t rwk_head_n_blocks(int64_t g) { return g >= 1 ? head_blocks(g) : 0; }
+
+int64_t rwk_head_stats_size(int64_t g, int64_t c) { return g >= 1 ? (int64_t)head_blocks(g) * (1 + 2 * c) : 0; }
+
+int64_t rwk_head_grad_size(int64_t c, int64_t p, int64_t nc) { return head_nv((int)c, (int)p, (int)nc); }
+
+int rwk_head_forward(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
+                     const float *bn_b, float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                     float momentum, float eps, int training, float *stats, const float *w1, const float *b1,
+                     const float *w2, const float *b2, float drop_p, uint64_t *rng_state, uint64_t *rng_used,
+                     float *mean_out, float *invstd_out, float *h1d_out, float *out, rwk_stream_t stream_) {
+    RWK_REQUIRE_PTR(k);
+    RWK_REQUIRE_PTR(bn_w);
+    RWK_REQUIRE_PTR(bn_b);
+    RWK_REQUIRE_PTR(running_mean);
+    RWK_REQUIRE_PTR(running_var);
+    RWK_REQUIRE_PTR(w1);
+    RWK_REQUIRE_PTR(b1);
+    RWK_REQUIRE_PTR(w2);
+    RWK_REQUIRE_PTR(b2);
+    RWK_REQUIRE_PTR(out);
+    if (!rwk_head_supported(g, c, p, nc)) return RWK_E_UNSUPPORTED;
+    if (drop_p < 0.f || drop_p >= 1.f) return RWK_E_SIZE;
+    const bool drop = training && drop_p > 0.f;
+    if (training) {
+        RWK_REQUIRE_PTR(stats);
+        RWK_REQUIRE_PTR(mean_out);
+        RWK_REQUIRE_PTR(invstd_out);
+    }
+    if (drop) {
+        RWK_REQUIRE_PTR(rng_state);
+        RWK_REQUIRE_PTR(rng_used);
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    const int blocks = head_blocks(g);
+    const HeadDims dm{(long long)g, (int)c, (int)p, (int)nc};
+    if (training) {
+        hipLaunchKernelGGL(head_stats_kernel, dim3(blocks), dim3(kBlock), 0, stream, k, (long long)g, (int)c, stats,
+                           drop ? (unsigned long long *)rng_state : nullptr,
+                           drop ? (unsigned long long *)rng_used : nullptr);
+        RWK_LAUNCH_CHECK();
+    }
+    const size_t lds = fwd_lds((int)c, (int)p, (int)nc);
+    const int rc = allow_lds(head_apply_kernel, lds);
+    if (rc != RWK_OK) return rc;
+    hipLaunchKernelGGL(head_apply_kernel, dim3(blocks), dim3(kBlock), lds, stream, k, dm, bn_w, bn_b, running_mean,
+                       running_var, (long long *)num_batches_tracked, momentum, eps, training, stats, blocks, w1, b1,
+                       w2, b2, drop_p, (const unsigned long long *)rng_used, mean_out, invstd_out, h1d_out, out);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
+int rwk_head_backward(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
+                      const float *bn_b, const float *mean, const float *invstd, int training, const float *w1,
+                      const float *w2, const float *h1d, const float *out, const float *d_out, float drop_p,
+                      float *dy, float *partials, float *grads, float *d_k, rwk_stream_t stream_) {
+    RWK_REQUIRE_PTR(k);
+    RWK_REQUIRE_PTR(bn_w);
+    RWK_REQUIRE_PTR(bn_b);
+    RWK_REQUIRE_PTR(mean);
+    RWK_REQUIRE_PTR(invstd);
+    RWK_REQUIRE_PTR(w1);
+    RWK_REQUIRE_PTR(w2);
+    RWK_REQUIRE_PTR(h1d);
+    RWK_REQUIRE_PTR(out);
+    RWK_REQUIRE_PTR(d_out);
+    RWK_REQUIRE_PTR(dy);
+    RWK_REQUIRE_PTR(partials);
+    RWK_REQUIRE_PTR(grads);
+    if (!rwk_head_supported(g, c, p, nc)) return RWK_E_UNSUPPORTED;
+    if (drop_p < 0.f || drop_p >= 1.f) return RWK_E_SIZE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int blocks = head_blocks(g);
+    const HeadDims dm{(long long)g, (int)c, (int)p, (int)nc};
+    const float keep_scale = (training && drop_p > 0.f) ? 1.f / (1.f - drop_p) : 1.f;
+    const size_t lds = bwd_lds((int)c, (int)p, (int)nc);
+    const int rc = allow_lds(head_bwd_tile_kernel, lds);
+    if (rc != RWK_OK) return rc;
+    hipLaunchKernelGGL(head_bwd_tile_kernel, dim3(blocks), dim3(kBlock), lds, stream, k, dm, bn_w, bn_b, mean, invstd,
+                       w1, w2, h1d, out, d_out, keep_scale, dy, partials);
+    RWK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(head_bwd_finish_kernel, dim3(blocks), dim3(kBlock), 0, stream, k, dm, bn_w, mean, invstd, dy,
+                       partials, blocks, training, grads, d_k);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
+}  // extern "C"

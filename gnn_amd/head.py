@@ -1,0 +1,96 @@
+"""Fused classifier head: ``log_softmax(fc2(dropout(relu(fc1(bn(k))))))`` (``rwgnn2/model.py:68-72``).
+
+The modules stay ordinary ``nn.BatchNorm1d`` / ``nn.Linear`` / ``nn.Dropout`` objects (same ``state_dict``);
+this function only replaces the ~35 small launches torch needs for their forward and backward by two HIP
+launches each way.  Batch statistics, running-statistics update and gradients follow torch's definitions; the
+dropout mask comes from the model's counter-based generator instead of torch's.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+__all__ = ["head_supported", "fused_head"]
+
+
+def head_supported(n_graphs: int, n_features: int, penultimate_dim: int, n_classes: int) -> bool:
+    return bool(_lib.load().rwk_head_supported(n_graphs, n_features, penultimate_dim, n_classes))
+
+
+class _FusedHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, k, bn_w, bn_b, w1, b1, w2, b2, running_mean, running_var, num_batches_tracked, momentum, eps,
+                training, drop_p, rng_state):
+        lib = _lib.load()
+        if not k.is_cuda:
+            raise RuntimeError("gnn_amd runs on HIP devices only (no CPU fallback)")
+        g, c = k.shape
+        p, nc = w1.shape[0], w2.shape[0]
+        dev = k.device
+        training = bool(training)
+        if training and g < 2:
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s"
+                             % (tuple(k.shape),))
+        drop = float(drop_p) if (training and drop_p and rng_state is not None) else 0.0
+        needs_grad = any(ctx.needs_input_grad[:7])
+        with torch.cuda.device(dev):
+            stream = _lib.current_stream(dev)
+            kc = k.detach().contiguous()
+            tensors = [t.detach().contiguous() for t in (bn_w, bn_b, w1, b1, w2, b2)]
+            bn_wc, bn_bc, w1c, b1c, w2c, b2c = tensors
+            out = torch.empty((g, nc), dtype=torch.float32, device=dev)
+            stats = torch.empty(lib.rwk_head_stats_size(g, c), dtype=torch.float32, device=dev) if training else None
+            keep = training or needs_grad
+            mean = torch.empty(c, dtype=torch.float32, device=dev) if keep else None
+            invstd = torch.empty(c, dtype=torch.float32, device=dev) if keep else None
+            h1d = torch.empty((g, p), dtype=torch.float32, device=dev) if needs_grad else None
+            rng_used = torch.empty(2, dtype=torch.int64, device=dev) if drop else None
+            _lib.check(lib.rwk_head_forward(
+                kc.data_ptr(), g, c, p, nc, bn_wc.data_ptr(), bn_bc.data_ptr(), running_mean.data_ptr(),
+                running_var.data_ptr(), _lib.ptr(num_batches_tracked), float(momentum), float(eps), int(training),
+                _lib.ptr(stats), w1c.data_ptr(), b1c.data_ptr(), w2c.data_ptr(), b2c.data_ptr(), drop,
+                _lib.ptr(rng_state) if drop else None, _lib.ptr(rng_used), _lib.ptr(mean), _lib.ptr(invstd),
+                _lib.ptr(h1d), out.data_ptr(), stream), "rwk_head_forward")
+        ctx.cfg = (training, drop)
+        ctx.save_for_backward(kc, bn_wc, bn_bc, w1c, w2c, mean, invstd, h1d, out)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        kc, bn_wc, bn_bc, w1c, w2c, mean, invstd, h1d, out = ctx.saved_tensors
+        training, drop = ctx.cfg
+        g, c = kc.shape
+        p, nc = w1c.shape[0], w2c.shape[0]
+        dev = kc.device
+        with torch.cuda.device(dev):
+            stream = _lib.current_stream(dev)
+            d_out = d_out.contiguous().float()
+            nv = lib.rwk_head_grad_size(c, p, nc)
+            blocks = lib.rwk_head_n_blocks(g)
+            dy = torch.empty((g, c), dtype=torch.float32, device=dev)
+            partials = torch.empty((blocks, nv), dtype=torch.float32, device=dev)
+            grads = torch.empty(nv, dtype=torch.float32, device=dev)
+            d_k = torch.empty((g, c), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+            _lib.check(lib.rwk_head_backward(
+                kc.data_ptr(), g, c, p, nc, bn_wc.data_ptr(), bn_bc.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                int(training), w1c.data_ptr(), w2c.data_ptr(), h1d.data_ptr(), out.data_ptr(), d_out.data_ptr(),
+                drop, dy.data_ptr(), partials.data_ptr(), grads.data_ptr(), _lib.ptr(d_k), stream),
+                "rwk_head_backward")
+        o = 0
+        d_w2 = grads[o:o + nc * p].view(nc, p); o += nc * p
+        d_b2 = grads[o:o + nc]; o += nc
+        d_w1 = grads[o:o + p * c].view(p, c); o += p * c
+        d_b1 = grads[o:o + p]; o += p
+        d_bn_w = grads[o:o + c]; o += c
+        d_bn_b = grads[o:o + c]
+        return (d_k, d_bn_w, d_bn_b, d_w1, d_b1, d_w2, d_b2) + (None,) * 8
+
+
+def fused_head(k, bn, fc1, fc2, drop_p: float, training: bool, rng_state=None):
+    """``log_softmax(fc2(dropout(relu(fc1(bn(k))))))`` with ``bn`` an ``nn.BatchNorm1d`` (affine, tracking running
+    statistics, float momentum) and ``fc1``/``fc2`` ``nn.Linear`` with bias."""
+    return _FusedHead.apply(k, bn.weight, bn.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, bn.running_mean,
+                            bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps, training, drop_p, rng_state)

@@ -2,9 +2,10 @@
 ``state_dict`` keys as ``rwgnn2/model.py:8-72`` (identical to ``rwgnn/model.py``), so that
 ``from gnn_amd import RW_NN`` can replace ``from model import RW_NN`` in ``rwgnn2/main.py:12``.
 
-Lines :32-67 of the reference forward run in hand-written HIP kernels (``gnn_amd/csrc``);
-the input projection ``fc`` and the head (:68-72: batch-norm, two linears, log-softmax) stay
-ordinary torch modules.
+Lines :32-67 of the reference forward run in hand-written HIP kernels (``gnn_amd/csrc``).  The input
+projection ``fc`` and the head (:68-72: batch-norm, two linears, log-softmax) stay ordinary torch modules
+in the ``state_dict``; the head's arithmetic runs in two fused launches each way when its sizes allow
+(``fused_head = False`` restores the torch operators).
 """
 from __future__ import annotations
 
@@ -14,6 +15,7 @@ import torch.nn.functional as F
 from torch.nn.parameter import Parameter
 
 from .function import FUSED_PROJECTION_MAX_INPUT_DIM, rw_kernel_layer, rw_kernel_layer_projected
+from .head import fused_head, head_supported
 from .structure import get_structure
 
 __all__ = ["RW_NN"]
@@ -44,6 +46,7 @@ class RW_NN(nn.Module):
         # HIP graph advances it on replay.  Not part of the state_dict (the reference has no such key).
         self.register_buffer("_rng_state", torch.zeros(2, dtype=torch.int64), persistent=False)
         self._rng_seeded = False
+        self.fused_head = True
         self.init_weights()
 
     def init_weights(self):
@@ -67,15 +70,29 @@ class RW_NN(nn.Module):
             k = k + 0.0 * (pre.sum() + self.features_hidden.sum() + self.adj_hidden.sum())
         else:
             k = self._rw(features, structure, drop)
+        if self._use_fused_head(k, drop):
+            if drop > 0.0 and not self._rng_seeded:
+                self._seed_from_torch()
+            return fused_head(k, self.bn, self.fc1, self.fc2, drop, self.training,
+                              self._rng_state if drop > 0.0 else None)
         out = self.bn(k)
         out = self.relu(self.fc1(out))
         out = self.dropout(out)
         out = self.fc2(out)
         return F.log_softmax(out, dim=1)
 
+    def _use_fused_head(self, k, drop):
+        bn = self.bn
+        return (self.fused_head and k.is_cuda and drop < 1.0 and bn.affine and bn.track_running_stats
+                and bn.momentum is not None and self.fc1.bias is not None and self.fc2.bias is not None
+                and head_supported(k.shape[0], k.shape[1], self.fc1.out_features, self.fc2.out_features))
+
+    def _seed_from_torch(self):
+        self.seed_dropout(int(torch.randint(0, 2 ** 62, (1,)).item()))
+
     def _rw(self, features, structure, drop):
         if drop > 0.0 and not self._rng_seeded:
-            self.seed_dropout(int(torch.randint(0, 2 ** 62, (1,)).item()))
+            self._seed_from_torch()
         rng = self._rng_state if drop > 0.0 else None
         if features.shape[1] <= FUSED_PROJECTION_MAX_INPUT_DIM:
             return rw_kernel_layer_projected(features, self.fc.weight, self.fc.bias, self.adj_hidden,

@@ -181,6 +181,43 @@ int rwk_fused_path(int64_t d, int64_t h, int64_t s, int64_t max_step);
 int64_t rwk_fused_stream_len(int64_t n, int64_t d, int64_t h, int64_t s, int64_t max_step, int backward);
 
 /* ---------------------------------------------------------------------------------------
+ * Classifier head   log_softmax(fc2(dropout(relu(fc1(bn(K))))))     replaces model.py:68-72
+ * (BatchNorm1d, Linear, ReLU, Dropout, Linear, log_softmax) and their backward: two launches
+ * each way instead of ~35.  K: (g, c) with c = max_step * hidden_graphs; w1: (p, c); w2: (nc, p).
+ * Limits: c <= 256, nc <= 32, p * c <= 4096 (rwk_head_supported); callers outside them keep
+ * the torch modules.
+ * ------------------------------------------------------------------------------------- */
+int rwk_head_supported(int64_t g, int64_t c, int64_t p, int64_t nc);
+/* workgroups of every head launch = rows of `stats` and of the backward `partials` */
+int64_t rwk_head_n_blocks(int64_t g);
+/* floats of `stats` (training forward): per workgroup {count, mean[c], M2[c]} */
+int64_t rwk_head_stats_size(int64_t g, int64_t c);
+/* floats of `grads`, and of one row of `partials`: [dW2 | db2 | dW1 | db1 | dbn_weight | dbn_bias] */
+int64_t rwk_head_grad_size(int64_t c, int64_t p, int64_t nc);
+
+/* training != 0: batch statistics (merged over the workgroups in a fixed order), running_mean /
+ * running_var / num_batches_tracked (may be NULL) updated as torch.nn.BatchNorm1d does, dropout
+ * with keep probability 1 - drop_p from the counter-based generator: {seed, offset} is read
+ * from rng_state, copied to rng_used, and the offset in rng_state is advanced by one (so a
+ * replayed HIP graph draws a fresh mask).  training == 0: running statistics, no dropout.
+ * mean_out, invstd_out (c each) and h1d_out (g, p: hidden activations after ReLU and dropout)
+ * are what rwk_head_backward needs; they may be NULL in inference.  out: (g, nc) log-probabilities. */
+int rwk_head_forward(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
+                     const float *bn_b, float *running_mean, float *running_var,
+                     int64_t *num_batches_tracked, float momentum, float eps, int training, float *stats,
+                     const float *w1, const float *b1, const float *w2, const float *b2, float drop_p,
+                     uint64_t *rng_state, uint64_t *rng_used, float *mean_out, float *invstd_out,
+                     float *h1d_out, float *out, rwk_stream_t stream);
+
+/* d_out: gradient of the log-probabilities.  dy: (g, c) scratch; partials: (rwk_head_n_blocks,
+ * rwk_head_grad_size) scratch; grads: rwk_head_grad_size floats out; d_k: (g, c) out or NULL. */
+int rwk_head_backward(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
+                      const float *bn_b, const float *mean, const float *invstd, int training,
+                      const float *w1, const float *w2, const float *h1d, const float *out,
+                      const float *d_out, float drop_p, float *dy, float *partials, float *grads,
+                      float *d_k, rwk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Input projection  X0 = sigmoid(features W^T + b)   replaces model.py:43 for narrow inputs
  * (input_dim <= 8; wider inputs go through a GEMM library and only the sigmoid is applied here)
  * ------------------------------------------------------------------------------------- */
