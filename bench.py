@@ -83,10 +83,11 @@ class Trainer:
         self.g_opt = None
 
     def fwd_bwd(self):
-        self.bucket.zero()
+        self.bucket.release()            # optimizer.zero_grad(set_to_none=True)
         out = self.model(self.adj, self.feats, self.gi)
         self.loss = F.cross_entropy(out, self.y)
         self.loss.backward()
+        self.bucket.gather()             # per-parameter gradients -> the flat bucket, one launch
 
     def step_eager(self):
         self.fwd_bwd()

@@ -35,9 +35,59 @@ adam_step_kernel(float *__restrict__ param, const float *__restrict__ grad, floa
     param[i] = p - (lr / corr[0]) * (m / denom);
 }
 
+constexpr int kGatherMax = 16;
+struct GatherArgs {
+    const float *src[kGatherMax];
+    long long dst_off[kGatherMax];
+    long long size[kGatherMax];
+};
+
+// chunk blockIdx.y of the argument table -> its slice of dst (zeros where the chunk has no source)
+__global__ void __launch_bounds__(kBlock)
+gather_chunks_kernel(GatherArgs a, float *__restrict__ dst) {
+    const int ch = blockIdx.y;
+    const float *src = a.src[ch];
+    float *out = dst + a.dst_off[ch];
+    const long long n = a.size[ch];
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)
+        out[i] = src ? src[i] : 0.f;
+}
+
 }  // namespace
 
 extern "C" {
+
+int rwk_gather_chunks(const float *const *srcs, const int64_t *sizes, int64_t n_chunks, float *dst,
+                      rwk_stream_t stream_) {
+    if (n_chunks < 0) return RWK_E_SIZE;
+    if (n_chunks == 0) return RWK_OK;
+    RWK_REQUIRE_PTR(srcs);
+    RWK_REQUIRE_PTR(sizes);
+    RWK_REQUIRE_PTR(dst);
+    hipStream_t stream = (hipStream_t)stream_;
+    long long off = 0;
+    for (int64_t c0 = 0; c0 < n_chunks; c0 += kGatherMax) {
+        GatherArgs a;
+        const int m = (int)(n_chunks - c0 < kGatherMax ? n_chunks - c0 : kGatherMax);
+        long long largest = 1;
+        for (int i = 0; i < kGatherMax; ++i) {
+            const bool used = i < m;
+            if (used && sizes[c0 + i] < 0) return RWK_E_SIZE;
+            a.src[i] = used ? srcs[c0 + i] : nullptr;
+            a.size[i] = used ? sizes[c0 + i] : 0;
+            a.dst_off[i] = off;
+            if (used) {
+                off += sizes[c0 + i];
+                if (sizes[c0 + i] > largest) largest = sizes[c0 + i];
+            }
+        }
+        long long bx = rwk_ceil_div(largest, kBlock);
+        if (bx > 1024) bx = 1024;
+        hipLaunchKernelGGL(gather_chunks_kernel, dim3((unsigned)bx, (unsigned)m), dim3(kBlock), 0, stream, a, dst);
+        RWK_LAUNCH_CHECK();
+    }
+    return RWK_OK;
+}
 
 int64_t rwk_adam_n_counters(int64_t n) { return n > 0 ? rwk_ceil_div(n, kBlock) : 0; }
 

@@ -63,6 +63,37 @@ class FlatGradBucket:
     def zero(self):
         self.flat.zero_()
 
+    def release(self):
+        """Detach ``p.grad`` from the bucket (host-side only): the next backward then hands each gradient over
+        without an accumulation launch per parameter; :meth:`gather` packs them into ``flat`` with one launch."""
+        for p in self.params:
+            p.grad = None
+
+    def gather(self):
+        """``flat`` = concatenation of the parameters' current gradients (zeros for a parameter without one)."""
+        grads = [None if p.grad is None else p.grad.detach().reshape(-1) for p in self.params]
+        if self.flat.is_cuda:
+            import ctypes
+            from . import _lib
+            lib = _lib.load()
+            grads = [None if g is None else g.contiguous().float() for g in grads]
+            n = len(grads)
+            srcs = (ctypes.c_void_p * n)(*[None if g is None else g.data_ptr() for g in grads])
+            sizes = (ctypes.c_int64 * n)(*[p.numel() for p in self.params])
+            with torch.cuda.device(self.flat.device):
+                _lib.check(lib.rwk_gather_chunks(srcs, sizes, n, self.flat.data_ptr(),
+                                                 _lib.current_stream(self.flat.device)), "rwk_gather_chunks")
+            self._keep = grads                     # the launch reads them asynchronously
+        else:                                       # host tensors (process-group tests on the gloo backend)
+            off = 0
+            for p, g in zip(self.params, grads):
+                n = p.numel()
+                if g is None:
+                    self.flat[off:off + n].zero_()
+                else:
+                    self.flat[off:off + n].copy_(g)
+                off += n
+
     def all_reduce(self, group=None, average: bool = True):
         """Sum (or mean) of the bucket over the ranks of ``group``; a no-op for a single process."""
         if not dist.is_available() or not dist.is_initialized():

@@ -254,6 +254,13 @@ int rwk_reduce_rows_to32(const float *in, int64_t p, int64_t v, float *out32, rw
  * graph replays correctly).
  * ------------------------------------------------------------------------------------- */
 int64_t rwk_adam_n_counters(int64_t n);
+
+/* dst = concatenation of n_chunks device arrays: srcs (HOST array of device pointers; a NULL
+ * entry stands for zeros) with sizes (HOST array of element counts).  The pointers travel as
+ * kernel arguments, 16 chunks per launch: per-parameter gradients -> one flat bucket for the
+ * all-reduce and the Adam launch, instead of one accumulation kernel per parameter. */
+int rwk_gather_chunks(const float *const *srcs, const int64_t *sizes, int64_t n_chunks, float *dst,
+                      rwk_stream_t stream);
 int rwk_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                   const float *lr, float beta1, float beta2, float eps, float weight_decay,
                   int64_t *step_counters, rwk_stream_t stream);
