@@ -24,9 +24,10 @@ namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kFwdBlock = 512;     // 8 wavefronts, each with its own 16 streams
-constexpr int kBwdBlock = 256;     // 4 wavefronts sharing 16 streams, splitting the hidden nodes s
-constexpr int kBwdWaves = 4;
-constexpr int kSwMax = 3;          // hidden nodes per wavefront in backward: S <= 12
+constexpr int kBwdBlock = 512;     // 8 wavefronts sharing 16 streams
+constexpr int kBwdWaves = 8;
+constexpr int kSMax = 12;          // hidden nodes per hidden graph (dZ accumulators are unrolled over them)
+constexpr int kGS = 20;            // row stride (floats) of a 16 x 16 gradient tile in LDS
 constexpr size_t kLdsBudget = 150 * 1024;
 
 struct DropCfg {
@@ -56,17 +57,14 @@ __device__ inline unsigned long long keep_bits(const DropCfg &c, uint32_t node, 
     return bits;
 }
 
-// four floats of a row starting at column off (zero beyond d); every load is unconditional
-__device__ inline float4 load4(const float *__restrict__ row, int d, int off, bool aligned) {
-    if (aligned && off + 3 < d) return *reinterpret_cast<const float4 *>(row + off);
-    float v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int k = off + e;
-        const float t = row[k < d ? k : d - 1];
-        v[e] = k < d ? t : 0.f;
-    }
-    return make_float4(v[0], v[1], v[2], v[3]);
+// Rows are 16-byte aligned (hidden_dim is a multiple of 4 on this path): one 16-byte load per piece.  A piece
+// that starts beyond d is read from the row's last piece instead and must be masked by the caller.
+__device__ inline float4 load4_raw(const float *__restrict__ row, int d, int off) {
+    return *reinterpret_cast<const float4 *>(row + (off < d ? off : d - 4));
+}
+__device__ inline float4 load4(const float *__restrict__ row, int d, int off) {
+    const float4 v = load4_raw(row, d, off);
+    return off < d ? v : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // Z rows of hidden graphs [16*hb, 16*hb+16), all steps and hidden nodes, into LDS: [i][s][16][ZS]
@@ -125,7 +123,6 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
     const bool has_stream = start_ll < n;
     const int start = has_stream ? (int)start_ll : 0;
     const int end = has_stream ? (int)(start_ll + stream_len < n ? start_ll + stream_len : n) : 0;
-    const bool aligned = (d & 3) == 0;
     DropCfg cfg;
     if (DROP) cfg = load_cfg(rng, t0, t1);
     const int lh = LT * h;
@@ -166,7 +163,7 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
         for (int i = 0; i < LT; ++i)
 #pragma unroll
             for (int tc = 0; tc < NT; ++tc) {
-                const float4 v = load4(x + i * step_stride + (size_t)node * d, d, 16 * tc + 4 * q, aligned);
+                const float4 v = load4(x + i * step_stride + (size_t)node * d, d, 16 * tc + 4 * q);
                 xv[i][tc] = valid ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         unsigned long long kb[4] = {0, 0, 0, 0};
@@ -180,9 +177,25 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
 #pragma unroll
             for (int r = 0; r < 4; ++r) node_acc[i][r] = 0.f;
         for (int ss = 0; ss < s; ++ss) {
+            // the LT tiles advance together: a dependent MFMA issues after 40 cycles, an independent one after 32
             f32x4 tt[LT];
 #pragma unroll
-            for (int i = 0; i < LT; ++i) tt[i] = tile_zx<NT>(zs + ((i * s + ss) * 16 + col) * ZS, q, xv[i]);
+            for (int i = 0; i < LT; ++i) tt[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tc = 0; tc < NT; ++tc) {
+                float4 a[LT];
+#pragma unroll
+                for (int i = 0; i < LT; ++i)
+                    a[i] = *reinterpret_cast<const float4 *>(zs + ((i * s + ss) * 16 + col) * ZS + 16 * tc + 4 * q);
+#pragma unroll
+                for (int i = 0; i < LT; ++i) tt[i] = RWK_MFMA(a[i].x, xv[i][tc].x, tt[i]);
+#pragma unroll
+                for (int i = 0; i < LT; ++i) tt[i] = RWK_MFMA(a[i].y, xv[i][tc].y, tt[i]);
+#pragma unroll
+                for (int i = 0; i < LT; ++i) tt[i] = RWK_MFMA(a[i].z, xv[i][tc].z, tt[i]);
+#pragma unroll
+                for (int i = 0; i < LT; ++i) tt[i] = RWK_MFMA(a[i].w, xv[i][tc].w, tt[i]);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 uint32_t kk = 0;
@@ -211,21 +224,34 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
 
 // ------------------------------------------------------------------------------------------------
 // backward
+//
+// A workgroup of 8 wavefronts owns 16 streams and one block of 16 hidden graphs.  Per position step:
+//   stage    the 16 x rows of every step i (fetched one step ahead into registers) go to LDS, with the node
+//            and graph ids and, once per (node, hidden graph), the dropout keep bits;
+//   phase A  wavefront w recomputes T_i = Z_i[ss] X_i^T for the hidden nodes ss = w, w+8 and turns them into
+//            the gradient tiles G_i[ss] (w.r.t. T_i; G_0 also carries the zx factor), written to LDS as
+//            [node][hidden graph];
+//   phase B  wavefront w owns the (step i, 16-column chunk tc) items w, w+8, ...: dX_i[:, tc] = sum_ss
+//            G_i[ss]^T Z_i[ss][:, tc] (stored straight from the accumulators) and dZ_i[ss][:, tc] += G_i[ss]
+//            X_i[:, tc] (kept in registers over the whole stream), both operands of G read from LDS.
+// Two barriers per step; x rows and keep bits are double-buffered.
 // ------------------------------------------------------------------------------------------------
-template <int LT, int NT, bool DROP>
+template <int LT, int NT, bool DROP, bool PERM>
 __global__ void __launch_bounds__(kBwdBlock)
 backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const int *__restrict__ gid,
                 const int *__restrict__ perm, const float *__restrict__ d_k, const float *__restrict__ counts_f32,
                 int n, int d, int h, int s, int stream_len, int n_calls, float scale, int normalize, uint32_t t0,
                 uint32_t t1, const unsigned long long *__restrict__ rng, float *__restrict__ dx_out,
                 float *__restrict__ dz_partials) {
-    constexpr int DPAD = 16 * NT, ZS = DPAD + 4, GS = 17;
+    constexpr int DPAD = 16 * NT, ZS = DPAD + 4;
+    constexpr int ITEMS = LT * NT, IPW = (ITEMS + kBwdWaves - 1) / kBwdWaves;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *zs = lds;                                         // [LT][s][16][ZS]
-    float *xt = zs + LT * s * 16 * ZS;                       // [LT][16 nodes][ZS]
-    float *gsc = xt + LT * 16 * ZS;                          // [waves][16][GS] transpose scratch
-    float *dxr = gsc + kBwdWaves * 16 * GS;                  // [waves][LT][16 nodes][DPAD]
-    __shared__ int t_node[16], t_gid[16];
+    float *zs = lds;                                          // [LT][s][16][ZS]
+    float *xt = zs + LT * s * 16 * ZS;                        // [2][LT][16 nodes][ZS]
+    float *gs = xt + 2 * LT * 16 * ZS;                        // [LT][s][16 nodes][kGS]
+    unsigned long long *kbits = reinterpret_cast<unsigned long long *>(gs + LT * s * 16 * kGS);   // [2][256]
+    int *t_node = reinterpret_cast<int *>(kbits + 2 * 256);   // [2][16]
+    float *dks = reinterpret_cast<float *>(t_node + 32);      // [2][LT][16 hidden graphs][16 slots]: scaled dK
 
     const int hb = blockIdx.y;
     const int tid = threadIdx.x;
@@ -233,34 +259,49 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
 
     const int lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, col = lane & 15;
-    const bool aligned = (d & 3) == 0;
     DropCfg cfg;
     if (DROP) cfg = load_cfg(rng, t0, t1);
     const int lh = LT * h;
     const size_t step_stride = (size_t)n * d;
     const int hq0 = 16 * hb + 4 * q;
-    float *my_gsc = gsc + wave * 16 * GS;
 
-    f32x4 dz[LT][kSwMax][NT];
+    f32x4 dz[IPW][kSMax];
 #pragma unroll
-    for (int i = 0; i < LT; ++i)
+    for (int it = 0; it < IPW; ++it)
 #pragma unroll
-        for (int sw = 0; sw < kSwMax; ++sw)
-#pragma unroll
-            for (int tc = 0; tc < NT; ++tc) dz[i][sw][tc] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float dp_cur[LT][4];
-#pragma unroll
-    for (int i = 0; i < LT; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dp_cur[i][r] = 0.f;
-    int g_cur = -1;
+        for (int ss = 0; ss < kSMax; ++ss) dz[it][ss] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // sorted position of stream slot `slot` at step t, or -1 past the end of the stream / of the batch
+    auto position = [&](int slot, int t) -> long long {
+        const long long cs = (long long)(blockIdx.x * 16 + slot) * stream_len;
+        const long long ce = cs + stream_len < n ? cs + stream_len : n;
+        return (cs < n && cs + t < ce) ? cs + t : -1;
+    };
 
-    // The 16 x rows of a step (one per stream) are fetched one step ahead into registers, so that their
-    // global-memory latency overlaps the MFMAs of the current step: thread -> (step i, node row, 16-byte chunk).
-    constexpr int kChunks = LT * 16 * (DPAD / 4);
+    constexpr int kChunks = LT * 16 * (DPAD / 4);             // 16-byte pieces of the x rows of one step
     constexpr int kLoads = (kChunks + kBwdBlock - 1) / kBwdBlock;
-    float4 pre[kLoads];
-    int pre_node = -1, pre_gid = -1;
+    // Everything fetched for step t+1 stays untouched in registers until the stage of step t+1: any arithmetic
+    // on a loaded value (even a select) would make the wavefront wait for the load right where it was issued.
+    float4 pre[kLoads];                                       // raw x pieces (rows at clamped positions)
+    bool pre_ok[kLoads];
+    // Thread tid < 256 serves the pair (slot tid & 15, hidden graph tid >> 4): node id for the keep bits and the
+    // dK entries of the slot's graph.  Graph ids are fetched two steps ahead, so that the dK loads that depend
+    // on them are issued without waiting.
+    const int my_slot = tid & 15, my_hl = tid >> 4;
+    const int my_hq = 16 * hb + my_hl;
+    const int my_hqc = my_hq < h ? my_hq : h - 1;
+    int pre_node = 0;                                         // raw
+    bool pre_node_ok = false;
+    float pre_dk[LT], pre_cnt = 1.f;                          // raw
+    bool pre_dk_ok = false;
+    int nxt_gid = 0;                                          // raw graph id of my_slot one step after `pre`
+    bool nxt_gid_ok = false;
+    int gc_cur = 0;                                           // clamped graph id the next prefetch uses
+    bool gc_ok = false;
+    auto load_gid = [&](int t) {
+        const long long pp = t < stream_len ? position(my_slot, t) : -1;
+        nxt_gid = gid[pp >= 0 ? pp : 0];
+        nxt_gid_ok = pp >= 0;
+    };
     auto prefetch = [&](int t) {
 #pragma unroll
         for (int k = 0; k < kLoads; ++k) {
@@ -268,31 +309,36 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
             const int ch = idx % (DPAD / 4);
             const int row = (idx / (DPAD / 4)) % 16;
             const int i = (idx / (DPAD / 4) / 16) % LT;
-            const long long cs = (long long)(blockIdx.x * 16 + row) * stream_len;
-            const long long pp = cs + t;
-            const long long ce = cs + stream_len < n ? cs + stream_len : n;
-            const bool ok = idx < kChunks && cs < n && pp < ce;
-            const long long pc = ok ? pp : 0;
-            const int node = perm ? perm[pc] : (int)pc;
-            const float4 v = load4(x + i * step_stride + (size_t)node * d, d, 4 * ch, aligned);
-            pre[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            const long long pp = idx < kChunks ? position(row, t) : -1;
+            const long long pc = pp >= 0 ? pp : 0;
+            const int node = PERM ? perm[pc] : (int)pc;
+            pre[k] = load4_raw(x + i * step_stride + (size_t)node * d, d, 4 * ch);
+            pre_ok[k] = pp >= 0;
         }
-        if (tid < 16) {
-            const long long cs = (long long)(blockIdx.x * 16 + tid) * stream_len;
-            const long long pp = cs + t;
-            const long long ce = cs + stream_len < n ? cs + stream_len : n;
-            const bool ok = cs < n && pp < ce;
-            const long long pc = ok ? pp : 0;
-            const int node = perm ? perm[pc] : (int)pc;
-            const int g = gid[pc];
-            pre_node = ok ? node : -1;
-            pre_gid = ok ? g : -1;
+        {
+            const long long pp = position(my_slot, t);
+            const long long pc = pp >= 0 ? pp : 0;
+            pre_node = PERM ? perm[pc] : (int)pc;
+            pre_node_ok = pp >= 0;
+            const int gc = gc_cur;                            // graph of my_slot at step t (fetched a step ago)
+            pre_dk_ok = gc_ok && my_hq < h && tid < 256;
+            if (normalize) pre_cnt = counts_f32[gc];
+#pragma unroll
+            for (int i = 0; i < LT; ++i) pre_dk[i] = d_k[(size_t)gc * lh + i * h + my_hqc];
+            load_gid(t + 1);
         }
     };
+    load_gid(0);
+    gc_cur = nxt_gid_ok ? nxt_gid : 0;
+    gc_ok = nxt_gid_ok;
     prefetch(0);
+    gc_cur = nxt_gid_ok ? nxt_gid : 0;                        // graph at step 1, for the prefetch issued in step 0
+    gc_ok = nxt_gid_ok;
 
     for (int t = 0; t < stream_len; ++t) {
-        __syncthreads();                                    // previous step's readers of xt / dxr are done
+        const int buf = t & 1;
+        // stage step t
+        float *xb = xt + buf * LT * 16 * ZS;
 #pragma unroll
         for (int k = 0; k < kLoads; ++k) {
             const int idx = tid + k * kBwdBlock;
@@ -300,61 +346,71 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                 const int ch = idx % (DPAD / 4);
                 const int row = (idx / (DPAD / 4)) % 16;
                 const int i = idx / (DPAD / 4) / 16;
-                *reinterpret_cast<float4 *>(xt + (i * 16 + row) * ZS + 4 * ch) = pre[k];
+                const float4 v = pre[k];
+                const bool ok = pre_ok[k];
+                const bool keep = ok && 4 * ch < d;
+                float4 o;
+                o.x = keep ? v.x : 0.f;
+                o.y = keep ? v.y : 0.f;
+                o.z = keep ? v.z : 0.f;
+                o.w = keep ? v.w : 0.f;
+                *reinterpret_cast<float4 *>(xb + (i * 16 + row) * ZS + 4 * ch) = o;
             }
         }
-        if (tid < 16) {
-            t_node[tid] = pre_node;
-            t_gid[tid] = pre_gid;
+        const int st_node = pre_node_ok ? pre_node : -1;
+        if (tid < 16) t_node[buf * 16 + tid] = st_node;
+        if (tid < 256) {
+            const float f = normalize ? scale / pre_cnt : scale;
+#pragma unroll
+            for (int i = 0; i < LT; ++i)
+                dks[((buf * LT + i) * 16 + my_hl) * 16 + my_slot] = pre_dk_ok ? pre_dk[i] * f : 0.f;
+            if (DROP)
+                kbits[buf * 256 + tid] = keep_bits(cfg, (uint32_t)(st_node >= 0 ? st_node : 0), (uint32_t)my_hq,
+                                                   n_calls);
         }
-        __syncthreads();
+        __syncthreads();                                      // step t staged; phase B of step t-1 finished
         if (t + 1 < stream_len) prefetch(t + 1);
 
-        const int node = t_node[col];
-        const bool valid = node >= 0;
-        const int g = valid ? t_gid[col] : g_cur;
-        if (g != g_cur) {                                   // first node of a graph in this column
-            g_cur = g;
-            float f = scale;
-            if (normalize) f /= counts_f32[g];
+        // ---------------- phase A ----------------
+        if (wave < s) {                                       // this wavefront has hidden nodes to do
+            float4 xv[LT][NT];                                // B of the recompute: X_i[node = col][16tc + 4q ..]
 #pragma unroll
             for (int i = 0; i < LT; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    dp_cur[i][r] = (hq0 + r < h) ? d_k[(size_t)g * lh + i * h + hq0 + r] * f : 0.f;
-        }
-        // operands that do not depend on s
-        float4 xv[LT][NT];                                  // B of the recompute: X_i[node = col][16tc + 4q ..]
-        float xq[LT][4][NT];                                // B of dZ: X_i[node = 4q + r][16tc + col]
+                for (int tc = 0; tc < NT; ++tc)
+                    xv[i][tc] = *reinterpret_cast<const float4 *>(xb + (i * 16 + col) * ZS + 16 * tc + 4 * q);
+            unsigned long long kb[4] = {0, 0, 0, 0};
+            if (DROP) {
 #pragma unroll
-        for (int i = 0; i < LT; ++i)
-#pragma unroll
-            for (int tc = 0; tc < NT; ++tc) {
-                xv[i][tc] = *reinterpret_cast<const float4 *>(xt + (i * 16 + col) * ZS + 16 * tc + 4 * q);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xq[i][r][tc] = xt[(i * 16 + 4 * q + r) * ZS + 16 * tc + col];
+                for (int r = 0; r < 4; ++r) kb[r] = kbits[buf * 256 + (4 * q + r) * 16 + col];
             }
-        unsigned long long kb[4] = {0, 0, 0, 0};
-        if (DROP) {
+            float dp_cur[LT][4];                              // scaled dK of (node col's graph, hidden graph 4q + r)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                kb[r] = keep_bits(cfg, (uint32_t)(valid ? node : 0), (uint32_t)(hq0 + r), n_calls);
-        }
-        f32x4 dxa[LT][NT];                                  // dX[node = 4q + r][16tc + col], this wave's share of s
+            for (int i = 0; i < LT; ++i)
 #pragma unroll
-        for (int i = 0; i < LT; ++i)
-#pragma unroll
-            for (int tc = 0; tc < NT; ++tc) dxa[i][tc] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-        for (int sw = 0; sw < kSwMax; ++sw) {
-            const int ss = wave + kBwdWaves * sw;
-            if (ss < s) {                                   // wave-uniform
+                for (int r = 0; r < 4; ++r) dp_cur[i][r] = dks[((buf * LT + i) * 16 + 4 * q + r) * 16 + col];
+            for (int ss = wave; ss < s; ss += kBwdWaves) {
+                // the LT tiles advance together, so that consecutive MFMAs never depend on each other
                 f32x4 tt[LT];
 #pragma unroll
-                for (int i = 0; i < LT; ++i) tt[i] = tile_zx<NT>(zs + ((i * s + ss) * 16 + col) * ZS, q, xv[i]);
-                // gradient tiles: gz (w.r.t. zx = Z0 X0^T) and gt[i] (w.r.t. t_i), rows h = 4q + r, column = node
-                f32x4 gz, gt[LT];
+                for (int i = 0; i < LT; ++i) tt[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int tc = 0; tc < NT; ++tc) {
+                    float4 a[LT];
+#pragma unroll
+                    for (int i = 0; i < LT; ++i)
+                        a[i] = *reinterpret_cast<const float4 *>(zs + ((i * s + ss) * 16 + col) * ZS + 16 * tc + 4 * q);
+#pragma unroll
+                    for (int i = 0; i < LT; ++i) tt[i] = RWK_MFMA(a[i].x, xv[i][tc].x, tt[i]);
+#pragma unroll
+                    for (int i = 0; i < LT; ++i) tt[i] = RWK_MFMA(a[i].y, xv[i][tc].y, tt[i]);
+#pragma unroll
+                    for (int i = 0; i < LT; ++i) tt[i] = RWK_MFMA(a[i].z, xv[i][tc].z, tt[i]);
+#pragma unroll
+                    for (int i = 0; i < LT; ++i) tt[i] = RWK_MFMA(a[i].w, xv[i][tc].w, tt[i]);
+                }
+                // gradient tiles: rows h = 4q + r, column = node; stored as [node][h]
+                float gt[LT][4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     uint32_t kk = 0;
@@ -365,76 +421,89 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                         w[i] = dp_cur[i][r];
                         if (DROP) w[i] = ((kk >> i) & 1u) ? w[i] : 0.f;
                     }
-                    float a = 2.f * w[0] * tt[0][r];        // step 0 contributes keep * zx^2
+                    float a0 = 2.f * w[0] * tt[0][r];        // step 0 contributes keep * zx^2
 #pragma unroll
                     for (int i = 1; i < LT; ++i) {
-                        a = fmaf(w[i], tt[i][r], a);
+                        a0 = fmaf(w[i], tt[i][r], a0);
                         gt[i][r] = w[i] * tt[0][r];
                     }
-                    gz[r] = a;
+                    gt[0][r] = a0;                            // step 0: everything flows through Z0, X0
                 }
-                gt[0] = gz;                                  // step 0: everything flows through Z0, X0
-                // dX_i += G_i^T Z_i[s]
 #pragma unroll
                 for (int i = 0; i < LT; ++i)
+                    *reinterpret_cast<float4 *>(gs + ((i * s + ss) * 16 + col) * kGS + 4 * q) =
+                        make_float4(gt[i][0], gt[i][1], gt[i][2], gt[i][3]);
+            }
+        }
+        __syncthreads();                                      // G tiles of step t complete
+        // Take the graph id fetched after the first barrier out of its load register HERE, while only that
+        // prefetch is outstanding: after the dX stores below, the in-order memory counter could tell it apart
+        // from them only by waiting for every store.
+        gc_cur = nxt_gid_ok ? nxt_gid : 0;
+        gc_ok = nxt_gid_ok;
+        asm volatile("" : "+v"(gc_cur));
+
+        // ---------------- phase B ----------------
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float *zrow = zs + ((i * s + ss) * 16 + 4 * q + r) * ZS + col;
+        for (int it = 0; it < IPW; ++it) {
+            const int item = wave + it * kBwdWaves;
+            if (item < ITEMS) {                               // wave-uniform
+                const int i = item / NT, tc = item % NT;
+                float xq[4];                                  // B of dZ: X_i[node = 4q + r][16tc + col]
 #pragma unroll
-                        for (int tc = 0; tc < NT; ++tc) dxa[i][tc] = RWK_MFMA(gt[i][r], zrow[16 * tc], dxa[i][tc]);
+                for (int r = 0; r < 4; ++r) xq[r] = xb[(i * 16 + 4 * q + r) * ZS + 16 * tc + col];
+                f32x4 dxa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ss = 0; ss < kSMax; ++ss) {
+                    if (ss < s) {                             // uniform
+                        const float *gtile = gs + (i * s + ss) * 16 * kGS;
+                        const float4 ga = *reinterpret_cast<const float4 *>(gtile + col * kGS + 4 * q);
+                        const float *zrow = zs + ((i * s + ss) * 16 + 4 * q) * ZS + 16 * tc + col;
+                        float zb[4], gb[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            zb[r] = zrow[r * ZS];             // Z_i[ss][h = 4q + r][16tc + col]
+                            gb[r] = gtile[(4 * q + r) * kGS + col];   // G_i[ss][h = col][node = 4q + r]
+                        }
+                        dxa = RWK_MFMA(ga.x, zb[0], dxa);
+                        dz[it][ss] = RWK_MFMA(gb[0], xq[0], dz[it][ss]);
+                        dxa = RWK_MFMA(ga.y, zb[1], dxa);
+                        dz[it][ss] = RWK_MFMA(gb[1], xq[1], dz[it][ss]);
+                        dxa = RWK_MFMA(ga.z, zb[2], dxa);
+                        dz[it][ss] = RWK_MFMA(gb[2], xq[2], dz[it][ss]);
+                        dxa = RWK_MFMA(ga.w, zb[3], dxa);
+                        dz[it][ss] = RWK_MFMA(gb[3], xq[3], dz[it][ss]);
                     }
-                // dZ_i[s] += G_i X_i: transpose G_i (h <-> node) through this wave's scratch
+                }
+                // the lane holds dX_i[node = 4q + r][16tc + col]
+                const int k = 16 * tc + col;
 #pragma unroll
-                for (int i = 0; i < LT; ++i) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) my_gsc[(4 * q + r) * GS + col] = gt[i][r];
-                    float gtr[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) gtr[r] = my_gsc[col * GS + 4 * q + r];   // G_i[h = col][node = 4q + r]
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int tc = 0; tc < NT; ++tc) dz[i][sw][tc] = RWK_MFMA(gtr[r], xq[i][r][tc], dz[i][sw][tc]);
+                for (int r = 0; r < 4; ++r) {
+                    const int nd = t_node[buf * 16 + 4 * q + r];
+                    if (nd >= 0 && k < d)
+                        dx_out[((size_t)hb * LT + i) * step_stride + (size_t)nd * d + k] = dxa[r];
                 }
             }
         }
-        // add the wavefronts' shares of dX in wavefront order and store the rows
-#pragma unroll
-        for (int i = 0; i < LT; ++i)
-#pragma unroll
-            for (int tc = 0; tc < NT; ++tc)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    dxr[((wave * LT + i) * 16 + 4 * q + r) * DPAD + 16 * tc + col] = dxa[i][tc][r];
-        __syncthreads();
-        for (int idx = tid; idx < LT * 16 * DPAD; idx += kBwdBlock) {
-            const int k = idx % DPAD;
-            const int row = (idx / DPAD) % 16;
-            const int i = idx / DPAD / 16;
-            const int nd = t_node[row];
-            if (nd < 0 || k >= d) continue;
-            float acc = 0.f;
-#pragma unroll
-            for (int w = 0; w < kBwdWaves; ++w) acc += dxr[((w * LT + i) * 16 + row) * DPAD + k];
-            dx_out[((size_t)hb * LT + i) * step_stride + (size_t)nd * d + k] = acc;
-        }
     }
 
-    // dZ: each wavefront owns its hidden nodes; lane holds dZ[h = 4q + r][16tc + col]
+    // dZ: the lane holds dZ_i[ss][h = 4q + r][16tc + col] of its items
     float *out = dz_partials + (size_t)blockIdx.x * LT * h * s * d;
 #pragma unroll
-    for (int sw = 0; sw < kSwMax; ++sw) {
-        const int ss = wave + kBwdWaves * sw;
-        if (ss >= s) continue;
+    for (int it = 0; it < IPW; ++it) {
+        const int item = wave + it * kBwdWaves;
+        if (item >= ITEMS) continue;
+        const int i = item / NT, tc = item % NT;
+        const int k = 16 * tc + col;
 #pragma unroll
-        for (int i = 0; i < LT; ++i)
+        for (int ss = 0; ss < kSMax; ++ss) {
+            if (ss >= s) continue;
 #pragma unroll
-            for (int tc = 0; tc < NT; ++tc)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int hq = hq0 + r, k = 16 * tc + col;
-                    if (hq < h && k < d) out[(((size_t)i * h + hq) * s + ss) * d + k] = dz[i][sw][tc][r];
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int hq = hq0 + r;
+                if (hq < h && k < d) out[(((size_t)i * h + hq) * s + ss) * d + k] = dz[it][ss][r];
+            }
+        }
     }
 }
 
@@ -453,8 +522,8 @@ inline int nt_of(int d) { return (d + 15) / 16; }
 inline size_t fwd_lds(int l, int s, int nt) { return (size_t)l * s * 16 * (16 * nt + 4) * sizeof(float); }
 inline size_t bwd_lds(int l, int s, int nt) {
     const int dpad = 16 * nt, zs = dpad + 4;
-    return ((size_t)l * s * 16 * zs + (size_t)l * 16 * zs + kBwdWaves * 16 * 17 + (size_t)kBwdWaves * l * 16 * dpad) *
-           sizeof(float);
+    return ((size_t)l * s * 16 * zs + 2 * (size_t)l * 16 * zs + (size_t)l * s * 16 * kGS) * sizeof(float) +
+           2 * 256 * sizeof(unsigned long long) + 32 * sizeof(int) + 2 * (size_t)l * 256 * sizeof(float);
 }
 
 template <int LT, int NT>
@@ -491,7 +560,7 @@ int launch_bwd(const Args &a) {
     if (dx_target == nullptr) return RWK_E_NULL;
 #define RWK_B(DROPV)                                                                                            \
     {                                                                                                           \
-        auto kern = backward_kernel<LT, NT, DROPV>;                                                             \
+        auto kern = a.perm ? backward_kernel<LT, NT, DROPV, true> : backward_kernel<LT, NT, DROPV, false>;     \
         if (lds > 64 * 1024) {                                                                                  \
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                                (int)lds);                                                       \
@@ -537,8 +606,8 @@ int by_l(const Args &a, bool bwd) {
 }  // namespace
 
 bool supported(int64_t d, int64_t h, int64_t s, int64_t max_step) {
-    if (d <= 4 || d > 64 || h < 1 || h > 64 || max_step < 1 || max_step > 4) return false;
-    if (s < 1 || s > kBwdWaves * kSwMax || s * max_step > 45) return false;
+    if (d <= 4 || d > 64 || (d & 3) != 0 || h < 1 || h > 64 || max_step < 1 || max_step > 4) return false;
+    if (s < 1 || s > kSMax || s * max_step > 45) return false;
     int nt = nt_of((int)d);
     if (nt == 3) nt = 4;
     return bwd_lds((int)max_step, (int)s, nt) + 256 <= kLdsBudget;
