@@ -84,6 +84,30 @@ __device__ inline void stage_z(const float *__restrict__ z, float *zs, int h, in
     }
 }
 
+// Diagnostic build only (-DRWK_STAMP): per-wavefront cycle shares of the backward step's segments.
+#ifdef RWK_STAMP
+__device__ unsigned long long rwk_stamp_buf[8 * 8];
+#define RWK_STAMP_DECL() unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0
+#define RWK_STAMP_AT(k)                                                      \
+    do {                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+        const unsigned long long now_ = __builtin_readcyclecounter();        \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+        if ((k) != 0) st_sum[k] += now_ - st_last;                           \
+        else if (st_last != 0) st_sum[0] += now_ - st_last;                  \
+        st_last = now_;                                                      \
+    } while (0)
+#define RWK_STAMP_FLUSH()                                                    \
+    do {                                                                     \
+        if (blockIdx.x == 3 && blockIdx.y == 0 && (threadIdx.x & 63) == 0)   \
+            for (int k_ = 0; k_ < 8; ++k_) rwk_stamp_buf[(threadIdx.x >> 6) * 8 + k_] = st_sum[k_]; \
+    } while (0)
+#else
+#define RWK_STAMP_DECL()
+#define RWK_STAMP_AT(k)
+#define RWK_STAMP_FLUSH()
+#endif
+
 #define RWK_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // acc(16 h x 16 nodes) = Z_i[s] X_i^T for this lane's fragments: zrow points at Z_i[s][h = lane&15][0]
@@ -270,11 +294,15 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     for (int it = 0; it < IPW; ++it)
 #pragma unroll
         for (int ss = 0; ss < kSMax; ++ss) dz[it][ss] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // sorted position of stream slot `slot` at step t, or -1 past the end of the stream / of the batch
-    auto position = [&](int slot, int t) -> long long {
+    // stream slot `slot` covers sorted positions first .. first + count - 1 (count = 0: no stream)
+    auto slot_first = [&](int slot) -> int {
         const long long cs = (long long)(blockIdx.x * 16 + slot) * stream_len;
-        const long long ce = cs + stream_len < n ? cs + stream_len : n;
-        return (cs < n && cs + t < ce) ? cs + t : -1;
+        return cs < n ? (int)cs : 0;
+    };
+    auto slot_count = [&](int slot) -> int {
+        const long long cs = (long long)(blockIdx.x * 16 + slot) * stream_len;
+        if (cs >= n) return 0;
+        return (int)(cs + stream_len < n ? stream_len : n - cs);
     };
 
     constexpr int kChunks = LT * 16 * (DPAD / 4);             // 16-byte pieces of the x rows of one step
@@ -283,6 +311,18 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     // on a loaded value (even a select) would make the wavefront wait for the load right where it was issued.
     float4 pre[kLoads];                                       // raw x pieces (rows at clamped positions)
     bool pre_ok[kLoads];
+    int x_first[kLoads], x_count[kLoads];                     // stream of the row this thread fetches pieces of
+    const float *x_base[kLoads];                              // x + step offset + piece offset
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) {
+        const int idx = tid + k * kBwdBlock;
+        const int ch = idx % (DPAD / 4);
+        const int row = (idx / (DPAD / 4)) % 16;
+        const int i = (idx / (DPAD / 4) / 16) % LT;
+        x_first[k] = slot_first(row);
+        x_count[k] = idx < kChunks ? slot_count(row) : 0;
+        x_base[k] = x + i * step_stride + (4 * ch < d ? 4 * ch : d - 4);
+    }
     // Thread tid < 256 serves the pair (slot tid & 15, hidden graph tid >> 4): node id for the keep bits and the
     // dK entries of the slot's graph.  Graph ids are fetched two steps ahead, so that the dK loads that depend
     // on them are issued without waiting.
@@ -297,29 +337,23 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     bool nxt_gid_ok = false;
     int gc_cur = 0;                                           // clamped graph id the next prefetch uses
     bool gc_ok = false;
+    const int my_first = slot_first(my_slot), my_count = slot_count(my_slot);
     auto load_gid = [&](int t) {
-        const long long pp = t < stream_len ? position(my_slot, t) : -1;
-        nxt_gid = gid[pp >= 0 ? pp : 0];
-        nxt_gid_ok = pp >= 0;
+        nxt_gid_ok = t < my_count;
+        nxt_gid = gid[nxt_gid_ok ? my_first + t : 0];
     };
     auto prefetch = [&](int t) {
 #pragma unroll
         for (int k = 0; k < kLoads; ++k) {
-            const int idx = tid + k * kBwdBlock;
-            const int ch = idx % (DPAD / 4);
-            const int row = (idx / (DPAD / 4)) % 16;
-            const int i = (idx / (DPAD / 4) / 16) % LT;
-            const long long pp = idx < kChunks ? position(row, t) : -1;
-            const long long pc = pp >= 0 ? pp : 0;
-            const int node = PERM ? perm[pc] : (int)pc;
-            pre[k] = load4_raw(x + i * step_stride + (size_t)node * d, d, 4 * ch);
-            pre_ok[k] = pp >= 0;
+            pre_ok[k] = t < x_count[k];
+            const int pc = pre_ok[k] ? x_first[k] + t : 0;
+            const int node = PERM ? perm[pc] : pc;
+            pre[k] = *reinterpret_cast<const float4 *>(x_base[k] + (size_t)node * d);
         }
         {
-            const long long pp = position(my_slot, t);
-            const long long pc = pp >= 0 ? pp : 0;
-            pre_node = PERM ? perm[pc] : (int)pc;
-            pre_node_ok = pp >= 0;
+            pre_node_ok = t < my_count;
+            const int pc = pre_node_ok ? my_first + t : 0;
+            pre_node = PERM ? perm[pc] : pc;
             const int gc = gc_cur;                            // graph of my_slot at step t (fetched a step ago)
             pre_dk_ok = gc_ok && my_hq < h && tid < 256;
             if (normalize) pre_cnt = counts_f32[gc];
@@ -328,6 +362,7 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
             load_gid(t + 1);
         }
     };
+    RWK_STAMP_DECL();
     load_gid(0);
     gc_cur = nxt_gid_ok ? nxt_gid : 0;
     gc_ok = nxt_gid_ok;
@@ -336,6 +371,7 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     gc_ok = nxt_gid_ok;
 
     for (int t = 0; t < stream_len; ++t) {
+        RWK_STAMP_AT(0);
         const int buf = t & 1;
         // stage step t
         float *xb = xt + buf * LT * 16 * ZS;
@@ -368,8 +404,11 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                 kbits[buf * 256 + tid] = keep_bits(cfg, (uint32_t)(st_node >= 0 ? st_node : 0), (uint32_t)my_hq,
                                                    n_calls);
         }
+        RWK_STAMP_AT(1);
         __syncthreads();                                      // step t staged; phase B of step t-1 finished
+        RWK_STAMP_AT(2);
         if (t + 1 < stream_len) prefetch(t + 1);
+        RWK_STAMP_AT(3);
 
         // ---------------- phase A ----------------
         if (wave < s) {                                       // this wavefront has hidden nodes to do
@@ -435,13 +474,16 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                         make_float4(gt[i][0], gt[i][1], gt[i][2], gt[i][3]);
             }
         }
+        RWK_STAMP_AT(4);
         __syncthreads();                                      // G tiles of step t complete
+        RWK_STAMP_AT(5);
         // Take the graph id fetched after the first barrier out of its load register HERE, while only that
         // prefetch is outstanding: after the dX stores below, the in-order memory counter could tell it apart
         // from them only by waiting for every store.
         gc_cur = nxt_gid_ok ? nxt_gid : 0;
         gc_ok = nxt_gid_ok;
         asm volatile("" : "+v"(gc_cur));
+        RWK_STAMP_AT(6);
 
         // ---------------- phase B ----------------
 #pragma unroll
@@ -452,19 +494,33 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                 float xq[4];                                  // B of dZ: X_i[node = 4q + r][16tc + col]
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xq[r] = xb[(i * 16 + 4 * q + r) * ZS + 16 * tc + col];
+                int nd[4];                                    // nodes of the dX rows this lane will store
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nd[r] = t_node[buf * 16 + 4 * q + r];
                 f32x4 dxa = {0.f, 0.f, 0.f, 0.f};
+                // operands of hidden node ss: ga = G_i[ss][node = col][h = 4q..4q+3] (A of dX),
+                // zb[r] = Z_i[ss][h = 4q + r][16tc + col] (B of dX), gb[r] = G_i[ss][h = col][node = 4q + r] (A of dZ)
+                float4 ga;
+                float zb[4], gb[4];
+                auto load_ops = [&](int ss, float4 &oga, float (&ozb)[4], float (&ogb)[4]) {
+                    const float *gtile = gs + (i * s + ss) * 16 * kGS;
+                    const float *zrow = zs + ((i * s + ss) * 16 + 4 * q) * ZS + 16 * tc + col;
+                    oga = *reinterpret_cast<const float4 *>(gtile + col * kGS + 4 * q);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ozb[r] = zrow[r * ZS];
+                        ogb[r] = gtile[(4 * q + r) * kGS + col];
+                    }
+                };
+                load_ops(0, ga, zb, gb);
 #pragma unroll
                 for (int ss = 0; ss < kSMax; ++ss) {
                     if (ss < s) {                             // uniform
-                        const float *gtile = gs + (i * s + ss) * 16 * kGS;
-                        const float4 ga = *reinterpret_cast<const float4 *>(gtile + col * kGS + 4 * q);
-                        const float *zrow = zs + ((i * s + ss) * 16 + 4 * q) * ZS + 16 * tc + col;
-                        float zb[4], gb[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            zb[r] = zrow[r * ZS];             // Z_i[ss][h = 4q + r][16tc + col]
-                            gb[r] = gtile[(4 * q + r) * kGS + col];   // G_i[ss][h = col][node = 4q + r]
-                        }
+                        // the next hidden node's operands are requested before this one's MFMAs are issued
+                        // (clamped index: the last request is a harmless repeat)
+                        float4 nga;
+                        float nzb[4], ngb[4];
+                        load_ops(ss + 1 < s ? ss + 1 : s - 1, nga, nzb, ngb);
                         dxa = RWK_MFMA(ga.x, zb[0], dxa);
                         dz[it][ss] = RWK_MFMA(gb[0], xq[0], dz[it][ss]);
                         dxa = RWK_MFMA(ga.y, zb[1], dxa);
@@ -473,20 +529,27 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                         dz[it][ss] = RWK_MFMA(gb[2], xq[2], dz[it][ss]);
                         dxa = RWK_MFMA(ga.w, zb[3], dxa);
                         dz[it][ss] = RWK_MFMA(gb[3], xq[3], dz[it][ss]);
+                        ga = nga;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            zb[r] = nzb[r];
+                            gb[r] = ngb[r];
+                        }
                     }
                 }
+                RWK_STAMP_AT(7);
                 // the lane holds dX_i[node = 4q + r][16tc + col]
                 const int k = 16 * tc + col;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int nd = t_node[buf * 16 + 4 * q + r];
-                    if (nd >= 0 && k < d)
-                        dx_out[((size_t)hb * LT + i) * step_stride + (size_t)nd * d + k] = dxa[r];
+                    if (nd[r] >= 0 && k < d)
+                        dx_out[((size_t)hb * LT + i) * step_stride + (size_t)nd[r] * d + k] = dxa[r];
                 }
             }
         }
     }
 
+    RWK_STAMP_FLUSH();
     // dZ: the lane holds dZ_i[ss][h = 4q + r][16tc + col] of its items
     float *out = dz_partials + (size_t)blockIdx.x * LT * h * s * d;
 #pragma unroll
@@ -633,6 +696,12 @@ int64_t stream_len(int64_t n, int64_t h) {
     const int64_t len = rwk_ceil_div(n, per_round * m);
     return len < 4 ? 4 : len;
 }
+
+#ifdef RWK_STAMP
+extern "C" int rwk_debug_read_stamps(unsigned long long *host64) {
+    return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(rwk_stamp_buf), sizeof(unsigned long long) * 64);
+}
+#endif
 
 int forward(const Args &a) { return by_l(a, false); }
 int backward(const Args &a) { return by_l(a, true); }
