@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(kBwdBlock)
 backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const int *__restrict__ gid,
                 const int *__restrict__ perm, const float *__restrict__ d_k, const float *__restrict__ counts_f32,
                 int n, int d, int h, int s, int stream_len, int n_calls, float scale, int normalize, uint32_t t0,
-                uint32_t t1, const unsigned long long *__restrict__ rng, float *__restrict__ dx_out,
+                uint32_t t1, const unsigned long long *__restrict__ rng, int n_hb, float *__restrict__ dx_out,
                 float *__restrict__ dz_partials) {
     constexpr int DPAD = 16 * NT, ZS = DPAD + 4;
     constexpr int ITEMS = LT * NT, IPW = (ITEMS + kBwdWaves - 1) / kBwdWaves;
@@ -277,9 +277,8 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     int *t_node = reinterpret_cast<int *>(kbits + 2 * 256);   // [2][16]
     float *dks = reinterpret_cast<float *>(t_node + 32);      // [2][LT][16 hidden graphs][16 slots]: scaled dK
 
-    const int hb = blockIdx.y;
+    int hb = 0;                                               // block of 16 hidden graphs being processed
     const int tid = threadIdx.x;
-    stage_z<LT, NT>(z, zs, h, s, d, hb, kBwdBlock);
 
     const int lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, col = lane & 15;
@@ -287,13 +286,9 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     if (DROP) cfg = load_cfg(rng, t0, t1);
     const int lh = LT * h;
     const size_t step_stride = (size_t)n * d;
-    const int hq0 = 16 * hb + 4 * q;
+    int hq0 = 4 * q;
 
     f32x4 dz[IPW][kSMax];
-#pragma unroll
-    for (int it = 0; it < IPW; ++it)
-#pragma unroll
-        for (int ss = 0; ss < kSMax; ++ss) dz[it][ss] = f32x4{0.f, 0.f, 0.f, 0.f};
     // stream slot `slot` covers sorted positions first .. first + count - 1 (count = 0: no stream)
     auto slot_first = [&](int slot) -> int {
         const long long cs = (long long)(blockIdx.x * 16 + slot) * stream_len;
@@ -327,8 +322,8 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     // dK entries of the slot's graph.  Graph ids are fetched two steps ahead, so that the dK loads that depend
     // on them are issued without waiting.
     const int my_slot = tid & 15, my_hl = tid >> 4;
-    const int my_hq = 16 * hb + my_hl;
-    const int my_hqc = my_hq < h ? my_hq : h - 1;
+    int my_hq = my_hl;
+    int my_hqc = my_hq < h ? my_hq : h - 1;
     int pre_node = 0;                                         // raw
     bool pre_node_ok = false;
     float pre_dk[LT], pre_cnt = 1.f;                          // raw
@@ -363,6 +358,18 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
         }
     };
     RWK_STAMP_DECL();
+    // The blocks of 16 hidden graphs are taken one after the other by the same workgroup, so that their shares of
+    // dX are added in block order by the lane that owns the element (no partial copies, no second launch).
+    for (hb = 0; hb < n_hb; ++hb) {
+    hq0 = 16 * hb + 4 * q;
+    my_hq = 16 * hb + my_hl;
+    my_hqc = my_hq < h ? my_hq : h - 1;
+    __syncthreads();                                          // readers of the previous block's LDS contents are done
+    stage_z<LT, NT>(z, zs, h, s, d, hb, kBwdBlock);
+#pragma unroll
+    for (int it = 0; it < IPW; ++it)
+#pragma unroll
+        for (int ss = 0; ss < kSMax; ++ss) dz[it][ss] = f32x4{0.f, 0.f, 0.f, 0.f};
     load_gid(0);
     gc_cur = nxt_gid_ok ? nxt_gid : 0;
     gc_ok = nxt_gid_ok;
@@ -497,6 +504,16 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                 int nd[4];                                    // nodes of the dX rows this lane will store
 #pragma unroll
                 for (int r = 0; r < 4; ++r) nd[r] = t_node[buf * 16 + 4 * q + r];
+                // dX so far (earlier blocks of hidden graphs): requested now, added after the MFMAs.  Agent-scope
+                // loads: the element was stored by this very lane, but a plain load could hit a stale L1 line.
+                const int kcol = 16 * tc + col < d ? 16 * tc + col : d - 1;
+                float old[4] = {0.f, 0.f, 0.f, 0.f};
+                if (hb > 0) {                                 // uniform
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        old[r] = __hip_atomic_load(dx_out + (size_t)i * step_stride + (size_t)(nd[r] >= 0 ? nd[r] : 0) * d + kcol,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 f32x4 dxa = {0.f, 0.f, 0.f, 0.f};
                 // operands of hidden node ss: ga = G_i[ss][node = col][h = 4q..4q+3] (A of dX),
                 // zb[r] = Z_i[ss][h = 4q + r][16tc + col] (B of dX), gb[r] = G_i[ss][h = col][node = 4q + r] (A of dZ)
@@ -543,7 +560,7 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (nd[r] >= 0 && k < d)
-                        dx_out[((size_t)hb * LT + i) * step_stride + (size_t)nd[r] * d + k] = dxa[r];
+                        dx_out[(size_t)i * step_stride + (size_t)nd[r] * d + k] = old[r] + dxa[r];
                 }
             }
         }
@@ -568,16 +585,7 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
             }
         }
     }
-}
-
-// dx[v] = sum over the hidden-graph blocks, in block order
-__global__ void __launch_bounds__(256)
-sum_blocks_kernel(const float *__restrict__ in, int n_blocks, long long v, float *__restrict__ out) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= v) return;
-    float acc = 0.f;
-    for (int b = 0; b < n_blocks; ++b) acc += in[(long long)b * v + i];
-    out[i] = acc;
+    }   // hidden-graph blocks
 }
 
 inline int nt_of(int d) { return (d + 15) / 16; }
@@ -616,11 +624,10 @@ int launch_fwd(const Args &a) {
 template <int LT, int NT>
 int launch_bwd(const Args &a) {
     const int hb = (a.h + 15) / 16;
-    const dim3 grid((unsigned)backward_blocks(a.n, a.stream_len), (unsigned)hb);
+    const dim3 grid((unsigned)backward_blocks(a.n, a.stream_len), 1u);
     const size_t lds = bwd_lds(LT, a.s, NT);
     const int n_calls = (a.s * a.max_step + 14) / 15;
-    float *dx_target = hb > 1 ? a.dx_partials : a.dx;
-    if (dx_target == nullptr) return RWK_E_NULL;
+    float *dx_target = a.dx;
 #define RWK_B(DROPV)                                                                                            \
     {                                                                                                           \
         auto kern = a.perm ? backward_kernel<LT, NT, DROPV, true> : backward_kernel<LT, NT, DROPV, false>;     \
@@ -631,17 +638,11 @@ int launch_bwd(const Args &a) {
         }                                                                                                       \
         hipLaunchKernelGGL(kern, grid, dim3(kBwdBlock), lds, a.stream, a.x, a.z, a.gid, a.perm, a.d_k, a.counts_f32, \
                            a.n, a.d, a.h, a.s, a.stream_len, n_calls, a.scale, a.normalize, a.t0, a.t1, a.rng,  \
-                           dx_target, a.dz_partials);                                                           \
+                           hb, dx_target, a.dz_partials);                                                           \
     }
     if (a.drop) RWK_B(true) else RWK_B(false)
 #undef RWK_B
     RWK_LAUNCH_CHECK();
-    if (hb > 1) {
-        const long long v = (long long)a.max_step * a.n * a.d;
-        hipLaunchKernelGGL(sum_blocks_kernel, dim3((unsigned)rwk_ceil_div(v, 256)), dim3(256), 0, a.stream,
-                           a.dx_partials, hb, v, a.dx);
-        RWK_LAUNCH_CHECK();
-    }
     return RWK_OK;
 }
 
@@ -679,8 +680,8 @@ bool supported(int64_t d, int64_t h, int64_t s, int64_t max_step) {
 int64_t backward_blocks(int64_t n, int64_t stream_len) { return rwk_ceil_div(rwk_ceil_div(n, stream_len), 16); }
 
 int64_t dx_partials_size(int64_t n, int64_t d, int64_t h, int64_t max_step) {
-    const int64_t hb = (h + 15) / 16;
-    return hb > 1 ? hb * max_step * n * d : 0;
+    (void)n; (void)d; (void)h; (void)max_step;
+    return 0;                                                 // the blocks of hidden graphs are added in place
 }
 
 // Forward workgroups hold 128 streams for one block of 16 hidden graphs, one workgroup per CU (the Z slab
