@@ -92,9 +92,46 @@ __global__ void segments_build_kernel(const int64_t *__restrict__ ids, int64_t n
 
 inline bool fits_i32(int64_t v) { return v >= 0 && v < 0x7FFFFFFFll; }
 
+// Batch assembly: node v of the batch is node src_node[v] of the data set; its stored entries are copied to
+// positions out_ptr[v].. of the batch's COO list with the column ids moved by col_delta[v] (new first node of
+// its graph minus old first node).  Rows keep their stored (column-sorted) order, so the list comes out
+// row-major sorted like scipy's lil -> coo conversion.
+__global__ void __launch_bounds__(kBlock)
+batch_gather_coo_kernel(const int64_t *__restrict__ ds_row_ptr, const int32_t *__restrict__ ds_col,
+                        const float *__restrict__ ds_val, const int64_t *__restrict__ src_node,
+                        const int64_t *__restrict__ col_delta, const int64_t *__restrict__ out_ptr, int64_t n,
+                        int64_t *__restrict__ rows, int64_t *__restrict__ cols, float *__restrict__ vals) {
+    const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (v >= n) return;
+    const int64_t sv = src_node[v];
+    const int64_t beg = ds_row_ptr[sv], end = ds_row_ptr[sv + 1];
+    const int64_t delta = col_delta[v];
+    int64_t o = out_ptr[v];
+    for (int64_t e = beg; e < end; ++e, ++o) {
+        rows[o] = v;
+        cols[o] = (int64_t)ds_col[e] + delta;
+        vals[o] = ds_val[e];
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int rwk_batch_gather_coo(const int64_t *ds_row_ptr, const int32_t *ds_col, const float *ds_val,
+                         const int64_t *src_node, const int64_t *col_delta, const int64_t *out_ptr, int64_t n,
+                         int64_t *rows, int64_t *cols, float *vals, rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(ds_row_ptr);
+    RWK_REQUIRE_PTR(src_node);
+    RWK_REQUIRE_PTR(col_delta);
+    RWK_REQUIRE_PTR(out_ptr);
+    if (n <= 0 || n >= 0x7FFFFFFFll) return RWK_E_SIZE;
+    hipLaunchKernelGGL(batch_gather_coo_kernel, dim3((unsigned)rwk_ceil_div(n, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, ds_row_ptr, ds_col, ds_val, src_node, col_delta, out_ptr, n, rows, cols,
+                       vals);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
 
 int rwk_coo_inspect(const int64_t *rows, const int64_t *cols, int64_t nnz, int64_t n, int32_t *flags,
                     rwk_stream_t stream) {

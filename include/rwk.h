@@ -82,6 +82,17 @@ int rwk_segments_build(const int64_t *ids_sorted, int64_t n, int64_t n_graphs, i
                        int32_t *seg_ptr, int64_t *counts, float *counts_f32, int32_t *empty,
                        rwk_stream_t stream);
 
+/* Batch assembly on the device (replaces the scipy LIL block-diagonal assembly of
+ * generate_batches, utils.py:47-85).  The data set is one block-diagonal CSR over all its
+ * nodes (ds_row_ptr int64 (N_all+1), ds_col int32 data-set node ids, ds_val).  For the n nodes
+ * of a batch: src_node[v] = data-set node, col_delta[v] = (first batch node of v's graph) -
+ * (first data-set node of v's graph), out_ptr[v] = exclusive prefix sum of the row lengths.
+ * Writes the batch's COO list (rows, cols int64, vals float32), row-major sorted, bit-identical
+ * to the reference's lil_matrix -> tocoo() result. */
+int rwk_batch_gather_coo(const int64_t *ds_row_ptr, const int32_t *ds_col, const float *ds_val,
+                         const int64_t *src_node, const int64_t *col_delta, const int64_t *out_ptr,
+                         int64_t n, int64_t *rows, int64_t *cols, float *vals, rwk_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * (1) CSR SpMM   y = A x (+ y)          replaces torch.spmm, model.py:55, and its backward
  * ------------------------------------------------------------------------------------- */
@@ -165,9 +176,8 @@ int rwk_fused_backward(const float *x, const float *z, const int32_t *gid, const
                        int normalize, const uint64_t *rng, float *dx, float *dz_partials,
                        float *workspace, rwk_stream_t stream);
 
-/* Floats of `workspace` rwk_fused_backward needs (0: pass NULL).  Non-zero only on the matrix-core
- * path with more than 16 hidden graphs, where each block of 16 hidden graphs writes its own share
- * of dx and the shares are then added in block order. */
+/* Floats of `workspace` rwk_fused_backward needs (0: pass NULL).  Currently always 0: on the
+ * matrix-core path the blocks of 16 hidden graphs are added into dx in place, in block order. */
 int64_t rwk_fused_backward_workspace(int64_t n, int64_t d, int64_t h, int64_t s, int64_t max_step);
 
 /* Which kernel family serves these hyper-parameters: 1 = register-resident vector-ALU kernels

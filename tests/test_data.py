@@ -1,0 +1,108 @@
+"""TU loader and device-side batch construction against the reference's own batches.
+
+The goldens ``mutag_b0`` / ``mutag_b1_eval`` / ``mutag_b2_norm`` hold the inputs the reference's ``load_data`` +
+``generate_batches(batch_size=64, shuffle=False)`` produced from its MUTAG files (``oracle/make_golden.py``); the
+same files are committed under ``tests/golden/MUTAG`` as data.  Everything here is integer / copy work: bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _golden import GoldenCase
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BATCHES = {0: "mutag_b0", 1: "mutag_b1_eval", 2: "mutag_b2_norm"}
+
+
+def host_batch(adj, features, y, ids):
+    """Plain numpy restatement of the loop body of utils.py:60-83."""
+    rows, cols, vals, feats, gi = [], [], [], [], []
+    off = 0
+    for j, g in enumerate(ids):
+        m = adj[g].tocoo()
+        order = np.lexsort((m.col, m.row))
+        rows.append(m.row[order].astype(np.int64) + off)
+        cols.append(m.col[order].astype(np.int64) + off)
+        vals.append(m.data[order].astype(np.float32))
+        feats.append(np.asarray(features[g], dtype=np.float64).astype(np.float32))
+        gi.append(np.full(m.shape[0], j, dtype=np.int64))
+        off += m.shape[0]
+    return (np.vstack([np.concatenate(rows), np.concatenate(cols)]), np.concatenate(vals), np.vstack(feats),
+            np.concatenate(gi), np.asarray([y[g] for g in ids], dtype=np.int64))
+
+
+def test_load_data_matches_reference_batches():
+    from gnn_amd.data import load_data
+    adj, features, y = load_data("MUTAG", False, root=ROOT)
+    assert len(adj) == 188 and sum(m.shape[0] for m in adj) == 3371
+    assert sorted(np.unique(y).tolist()) == [-1, 1]
+    y = np.unique(y, return_inverse=True)[1]             # main.py:39-40 (LabelEncoder): sorted labels -> 0..C-1
+    for b, name in BATCHES.items():
+        c = GoldenCase(name)
+        ids = list(range(64 * b, min(64 * b + 64, 188)))
+        idx, vals, feats, gi, yy = host_batch(adj, features, y, ids)
+        assert np.array_equal(idx, c["coo_indices"])
+        assert np.array_equal(vals, c["coo_values"])
+        assert np.array_equal(feats, c["features"])
+        assert np.array_equal(gi, c["graph_indicator"])
+        assert np.array_equal(yy, c["y"])
+
+
+def test_one_hot_node_labels():
+    from gnn_amd.data import load_data
+    adj, features, _ = load_data("MUTAG", True, root=ROOT)
+    labels = np.loadtxt(os.path.join(ROOT, "MUTAG", "MUTAG_node_labels.txt"), dtype=np.int64)
+    x = np.vstack(features)
+    assert x.shape == (3371, np.unique(labels).size)
+    assert np.array_equal(x.sum(axis=1), np.ones(3371))
+    assert np.array_equal(np.unique(labels)[x.argmax(axis=1)], labels)      # column order = sorted labels
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_generate_batches_on_device(shuffle):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gnn_amd.data import generate_batches, load_data
+    dev = torch.device("cuda:0")
+    adj, features, y = load_data("MUTAG", False, root=ROOT)
+    y = np.unique(y, return_inverse=True)[1]
+    np.random.seed(7)
+    a_l, f_l, g_l, y_l = generate_batches(adj, features, y, 64, dev, shuffle=shuffle)
+    np.random.seed(7)
+    index = np.random.permutation(188) if shuffle else np.arange(188)
+    assert len(a_l) == 3
+    for b in range(3):
+        ids = index[64 * b:min(64 * b + 64, 188)]
+        idx, vals, feats, gi, yy = host_batch(adj, features, y, ids)
+        assert a_l[b].shape == (gi.size, gi.size) and a_l[b].dtype == torch.float32
+        assert np.array_equal(a_l[b]._indices().cpu().numpy(), idx)
+        assert np.array_equal(a_l[b]._values().cpu().numpy(), vals)
+        assert f_l[b].dtype == torch.float32 and np.array_equal(f_l[b].cpu().numpy(), feats)
+        assert g_l[b].dtype == torch.int64 and np.array_equal(g_l[b].cpu().numpy(), gi)
+        assert y_l[b].dtype == torch.int64 and np.array_equal(y_l[b].cpu().numpy(), yy)
+        if not shuffle:                                  # the reference's own batches
+            c = GoldenCase(BATCHES[b])
+            assert np.array_equal(idx, c["coo_indices"]) and np.array_equal(feats, c["features"])
+
+
+@pytest.mark.gpu
+def test_batches_feed_the_model():
+    """End to end on the build's own stack: files -> device batches -> RW_NN forward/backward."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.nn.functional as F
+    from gnn_amd import RW_NN
+    from gnn_amd.data import generate_batches, load_data
+    dev = torch.device("cuda:0")
+    adj, features, y = load_data("MUTAG", False, root=ROOT)
+    y = np.unique(y, return_inverse=True)[1]
+    a_l, f_l, g_l, y_l = generate_batches(adj, features, y, 64, dev)
+    torch.manual_seed(0)
+    model = RW_NN(1, 2, 16, 5, 4, 32, False, 2, 0.2, dev).to(dev).train()
+    out = model(a_l[0], f_l[0], g_l[0])
+    F.cross_entropy(out, y_l[0]).backward()
+    assert out.shape == (64, 2) and torch.isfinite(out).all()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
