@@ -101,8 +101,18 @@ reduce_rows_level1_kernel(const float *__restrict__ in, long long p, long long v
     long long r1 = r0 + rows_per_block;
     if (r1 > p) r1 = p;
     float acc = 0.f;
-    if (col < v)
-        for (long long r = r0 + slice; r < r1; r += 4) acc += in[r * v + col];
+    if (col < v) {
+        long long r = r0 + slice;
+        for (; r + 12 < r1; r += 16) {                  // four rows in flight, added in row order
+            const float a0 = in[r * v + col], a1 = in[(r + 4) * v + col], a2 = in[(r + 8) * v + col],
+                        a3 = in[(r + 12) * v + col];
+            acc += a0;
+            acc += a1;
+            acc += a2;
+            acc += a3;
+        }
+        for (; r < r1; r += 4) acc += in[r * v + col];
+    }
     part[slice][lane] = acc;
     __syncthreads();
     if (slice == 0 && col < v)
@@ -115,7 +125,15 @@ reduce_rows_final_kernel(const float *__restrict__ in, int p, long long v, float
     const long long col = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (col >= v) return;
     float acc = 0.f;
-    for (int r = 0; r < p; ++r) acc += in[(long long)r * v + col];
+    int r = 0;
+    for (; r + 7 < p; r += 8) {                         // eight rows in flight, added in row order
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = in[(long long)(r + u) * v + col];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += a[u];
+    }
+    for (; r < p; ++r) acc += in[(long long)r * v + col];
     out[col] = acc;
 }
 
