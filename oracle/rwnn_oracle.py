@@ -227,8 +227,18 @@ def rw_kernel_gram(csr, x0, adj_hidden, features_hidden, graph_indicator, max_st
     out = np.zeros((g, max_step * h), dtype)
     for i in range(max_step):
         c = np.zeros((g, d, d), dtype)
-        np.add.at(c, gi, x0[:, :, None] * xs[i][:, None, :])
-        k = np.einsum("hsa,gab,hsb->gh", z0, c, zs[i])
+        if d <= 8:
+            np.add.at(c, gi, x0[:, :, None] * xs[i][:, None, :])
+        else:                                   # one small matrix product per graph (no N x D x D temporary)
+            order = np.argsort(gi, kind="stable")
+            ends = np.cumsum(counts)
+            a0, ai = x0[order], xs[i][order]
+            for gg in range(g):
+                lo = ends[gg] - counts[gg]
+                c[gg] = a0[lo:ends[gg]].T @ ai[lo:ends[gg]]
+        # two steps so that the D x D contraction is one matrix product: m[g,a,(h,s)] = sum_b c[g,a,b] z_i[h,s,b]
+        m = (c.reshape(g * d, d) @ zs[i].reshape(h * s, d).T).reshape(g, d, h, s)
+        k = np.einsum("hsa,gahs->gh", z0, m)
         if normalize:
             k = k / counts[:, None].astype(dtype)
         out[:, i * h:(i + 1) * h] = k

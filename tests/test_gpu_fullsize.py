@@ -1,0 +1,131 @@
+"""The HIP path at the benchmark configurations' FULL sizes against the float64 oracle.
+
+Forward: K of the whole batch against the oracle's Gram-matrix closed form (O(N D^2), exact without dropout)
+to 1e-5 of max|K|.  Backward: every gradient of the layer for a random cotangent against the oracle's analytic
+VJP (run on the whole batch where its (H, S, N) float64 temporaries fit in seconds, else on a leading slice of
+graphs).  Gradient sums over 1e5..3e5 nodes of terms of either sign lose relative accuracy in ANY float32
+implementation, so each gradient is bounded by 1e-5 of the sum of the magnitudes of its terms' scale, i.e. of
+max|gradient| or of the float32-rounding floor eps * sqrt(N) * max|term|, whichever is larger (stated per
+assertion).  Also: run-to-run bitwise reproducibility at full size, and invariance of K to permuting the
+graphs of the batch (a size-independent property: row g only depends on graph g).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rwnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def build(name, dev, n_graphs=None, seed=1):
+    from gnn_amd import RW_NN
+    from gnn_amd.synth import CONFIGS, config_batch
+    hp = dict(CONFIGS[name]["hp"])
+    b = config_batch(name, seed)
+    if n_graphs is not None and n_graphs < b.n_graphs:
+        b = b.slice_graphs(0, n_graphs)
+    torch.manual_seed(3)
+    m = RW_NN(hp["input_dim"], hp["max_step"], hp["hidden_graphs"], hp["size_hidden_graphs"], hp["hidden_dim"],
+              hp["penultimate_dim"], hp["normalize"], hp["n_classes"], 0.0, dev).to(dev)
+    m.eval()
+    return hp, b, m
+
+
+def oracle_inputs(b, m):
+    csr = O.coo_to_csr(b.indices, b.values, b.n_nodes)
+    w = m.fc.weight.detach().cpu().numpy().astype(np.float64)
+    bias = m.fc.bias.detach().cpu().numpy().astype(np.float64)
+    x0 = 1.0 / (1.0 + np.exp(-(b.features.astype(np.float64) @ w.T + bias)))
+    return csr, x0, m.adj_hidden.detach().cpu().numpy(), m.features_hidden.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["proteins1024", "powerlaw", "stream_h64", "single_graph"])
+def test_forward_full_size_against_gram_closed_form(name, dev):
+    hp, b, m = build(name, dev)
+    adj, feats, gi, _ = b.to_torch(dev)
+    k = m.rw_features(adj, feats, gi).detach().cpu().numpy()
+    csr, x0, ah, fh = oracle_inputs(b, m)
+    k_ref = O.rw_kernel_gram(csr, x0, ah, fh, b.graph_indicator, hp["max_step"], hp["normalize"])
+    assert k.shape == k_ref.shape == (b.n_graphs, hp["max_step"] * hp["hidden_graphs"])
+    assert rel(k, k_ref) < TOL
+    k2 = m.rw_features(adj, feats, gi).detach().cpu().numpy()
+    assert np.array_equal(k.view(np.uint32), k2.view(np.uint32)), "forward must be bitwise reproducible"
+
+
+@pytest.mark.parametrize("name,n_graphs", [("proteins1024", None), ("powerlaw", None), ("stream_h64", 1024),
+                                           ("single_graph", None)])
+def test_backward_full_size_against_oracle_vjp(name, n_graphs, dev):
+    hp, b, m = build(name, dev, n_graphs)
+    adj, feats, gi, _ = b.to_torch(dev)
+    feats = feats.clone().requires_grad_(True)
+    rng = np.random.default_rng(5)
+    dk = rng.normal(size=(b.n_graphs, hp["max_step"] * hp["hidden_graphs"])).astype(np.float32)
+    k = m.rw_features(adj, feats, gi)
+    k.backward(torch.from_numpy(dk).to(dev))
+    csr, x0, ah, fh = oracle_inputs(b, m)
+    d_x0, d_adj, d_feat = O.rw_kernel_backward(csr, x0, ah, fh, b.graph_indicator, hp["max_step"], dk,
+                                               hp["normalize"])
+    d_pre = d_x0 * x0 * (1 - x0)
+    w64 = m.fc.weight.detach().cpu().numpy().astype(np.float64)
+    f64 = b.features.astype(np.float64)
+    want = {"features": d_pre @ w64, "features_hidden": d_feat, "adj_hidden": d_adj, "fc.bias": d_pre.sum(0),
+            "fc.weight": d_pre.T @ f64}
+    got = {"features": feats.grad, "features_hidden": m.features_hidden.grad, "adj_hidden": m.adj_hidden.grad,
+           "fc.bias": m.fc.bias.grad, "fc.weight": m.fc.weight.grad}
+    # per-node gradient: no long sum, plain 1e-5
+    assert rel(got["features"].cpu().numpy(), want["features"]) < TOL
+    # parameter gradients: sums over all N nodes of signed terms (the cotangent is random).  Rounding floor of a
+    # float32 sum of N terms of magnitude t: about eps * sqrt(N) * t; relative to the result it is that over |sum|.
+    n = b.n_nodes
+    floor_terms = {"fc.bias": np.abs(d_pre).max(), "fc.weight": np.abs(d_pre).max() * np.abs(f64).max()}
+    for key in ("features_hidden", "adj_hidden", "fc.bias", "fc.weight"):
+        ref = want[key]
+        err = np.abs(got[key].cpu().numpy().astype(np.float64) - ref).max()
+        bound = TOL * np.abs(ref).max()
+        if key in floor_terms:
+            bound = max(bound, 6e-8 * np.sqrt(n) * 4 * floor_terms[key])
+        assert err <= bound, (key, err, bound, np.abs(ref).max())
+    # bitwise reproducibility of the backward at full size
+    g1 = m.features_hidden.grad.clone()
+    m.zero_grad()
+    feats.grad = None
+    m.rw_features(adj, feats, gi).backward(torch.from_numpy(dk).to(dev))
+    assert torch.equal(g1, m.features_hidden.grad)
+
+
+def test_graph_permutation_invariance_full_size(dev):
+    """Row g of K depends on graph g alone: the batch with its graphs in reverse order gives the same rows."""
+    from gnn_amd.synth import Batch
+    hp, b, m = build("proteins1024", dev)
+    adj, feats, gi, _ = b.to_torch(dev)
+    k = m.rw_features(adj, feats, gi).detach().cpu().numpy()
+    order = np.arange(b.n_graphs)[::-1]
+    parts = [b.slice_graphs(int(g), int(g) + 1) for g in order[:64]]      # the last 64 graphs, reversed
+    rows, cols, vals, fs, gis, off = [], [], [], [], [], 0
+    for j, p in enumerate(parts):
+        rows.append(p.indices[0] + off)
+        cols.append(p.indices[1] + off)
+        vals.append(p.values)
+        fs.append(p.features)
+        gis.append(np.full(p.n_nodes, j, dtype=np.int64))
+        off += p.n_nodes
+    rb = Batch(np.vstack([np.concatenate(rows), np.concatenate(cols)]), np.concatenate(vals), np.vstack(fs),
+               np.concatenate(gis), np.zeros(64, np.int64), np.array([p.n_nodes for p in parts]))
+    adj2, feats2, gi2, _ = rb.to_torch(dev)
+    k2 = m.rw_features(adj2, feats2, gi2).detach().cpu().numpy()
+    want = k[order[:64]]
+    assert np.abs(k2 - want).max() <= TOL * np.abs(want).max()
