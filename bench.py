@@ -64,63 +64,7 @@ def parse_args():
     return ap.parse_args()
 
 
-class Trainer:
-    """The reference's train() closure, with the gradients in one flat bucket."""
-
-    def __init__(self, model, batch_t, world, optimizer="flat"):
-        from gnn_amd.dp import FlatGradBucket
-        from gnn_amd.optim import FlatAdam
-        self.model = model
-        self.adj, self.feats, self.gi, self.y = batch_t
-        self.bucket = FlatGradBucket(model)
-        self.world = world
-        if optimizer == "flat":       # same arithmetic as torch.optim.Adam, one launch (main.py:79: lr 1e-2)
-            self.opt = FlatAdam(model, self.bucket, lr=1e-2)
-        else:
-            self.opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True, foreach=True)
-        self.loss = None
-        self.g_fb = None
-        self.g_opt = None
-
-    def fwd_bwd(self):
-        self.bucket.release()            # optimizer.zero_grad(set_to_none=True)
-        out = self.model(self.adj, self.feats, self.gi)
-        self.loss = F.cross_entropy(out, self.y)
-        self.loss.backward()
-        self.bucket.gather()             # per-parameter gradients -> the flat bucket, one launch
-
-    def step_eager(self):
-        self.fwd_bwd()
-        if self.world > 1:
-            self.bucket.all_reduce()
-        self.opt.step()
-
-    def capture(self):
-        """Capture forward+backward and the Adam update as two HIP graphs; the (tiny) gradient all-reduce
-        between them stays an ordinary RCCL call on the same stream."""
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(3):
-                self.step_eager()
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        # Drop the warm-up's autograd graph before capturing: its AccumulateGrad nodes are bound to the warm-up
-        # stream, and reusing them would fork the captured backward over two streams (torch warns about it; the
-        # forked replay was seen to feed stale gradients to the random-walk layer).
-        self.loss = None
-        self.g_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fb):
-            self.fwd_bwd()
-        self.g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_opt):
-            self.opt.step()
-
-    def step_graph(self):
-        self.g_fb.replay()
-        if self.world > 1:
-            self.bucket.all_reduce()
-        self.g_opt.replay()
+from gnn_amd.trainer import Trainer  # noqa: E402  (the step being timed)
 
 
 def tile_batch(batch_t, k):

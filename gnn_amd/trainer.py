@@ -1,0 +1,82 @@
+"""The reference's training step (``rwgnn2/main.py:82-88``) with the launch overhead taken out.
+
+``train()`` in the reference is: ``optimizer.zero_grad()``, ``model(adj, features, graph_indicator)``,
+``F.cross_entropy``, ``backward()``, ``optimizer.step()``.  On an MI355X the kernels of one such step on a
+1024-graph batch take about 0.2 ms, less than the host needs to launch them one by one, so ``Trainer`` offers
+the same step (a) eagerly and (b) captured once per batch into two HIP graphs (forward+backward, optimiser)
+that are replayed every epoch; batches are reused every epoch in the reference (``main.py:70-72,103-106``),
+which is what makes capture worthwhile.  Gradients live in one flat bucket (one all-reduce under data
+parallelism, one Adam launch).  The dropout generator's state lives on the device, so every replay draws
+fresh masks.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from .dp import FlatGradBucket
+from .optim import FlatAdam
+
+__all__ = ["Trainer"]
+
+
+class Trainer:
+    """One model, one resident batch ``(adj, features, graph_indicator, y)``.
+
+    ``world`` > 1: the flat gradient bucket is all-reduced (mean) over the default process group between the
+    backward and the optimiser step.  ``optimizer``: "flat" (``gnn_amd.optim.FlatAdam``, same arithmetic as
+    ``torch.optim.Adam``, one launch) or "torch" (``torch.optim.Adam(capturable=True)``).
+    """
+
+    def __init__(self, model, batch_t, world: int = 1, optimizer: str = "flat", lr: float = 1e-2):
+        self.model = model
+        self.adj, self.feats, self.gi, self.y = batch_t
+        self.bucket = FlatGradBucket(model)
+        self.world = world
+        if optimizer == "flat":       # main.py:79: Adam, lr 1e-2
+            self.opt = FlatAdam(model, self.bucket, lr=lr)
+        else:
+            self.opt = torch.optim.Adam(model.parameters(), lr=lr, capturable=True, foreach=True)
+        self.loss = None
+        self.g_fb = None
+        self.g_opt = None
+
+    def fwd_bwd(self):
+        self.bucket.release()            # optimizer.zero_grad(set_to_none=True)
+        out = self.model(self.adj, self.feats, self.gi)
+        self.loss = F.cross_entropy(out, self.y)
+        self.loss.backward()
+        self.bucket.gather()             # per-parameter gradients -> the flat bucket, one launch
+
+    def step_eager(self):
+        self.fwd_bwd()
+        if self.world > 1:
+            self.bucket.all_reduce()
+        self.opt.step()
+
+    def capture(self):
+        """Capture forward+backward and the Adam update as two HIP graphs; the (tiny) gradient all-reduce
+        between them stays an ordinary RCCL call on the same stream."""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                self.step_eager()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        # Drop the warm-up's autograd graph before capturing: its AccumulateGrad nodes are bound to the warm-up
+        # stream, and reusing them would fork the captured backward over two streams (torch warns about it; the
+        # forked replay was seen to feed stale gradients to the random-walk layer).
+        self.loss = None
+        self.g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fb):
+            self.fwd_bwd()
+        self.g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_opt):
+            self.opt.step()
+
+    def step_graph(self):
+        self.g_fb.replay()
+        if self.world > 1:
+            self.bucket.all_reduce()
+        self.g_opt.replay()
