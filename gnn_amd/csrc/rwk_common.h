@@ -99,6 +99,44 @@ __device__ static inline float rwk_dpp(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
 
+// Sums of V = 8 or 16 per-lane values over the 16 lanes of a DPP row at about a third of the cost of V
+// butterflies: at every step a lane keeps one half of its values and adds the same half received from its
+// partner (15-l, then 7-l within 8 lanes, then 3-l within 4, then l^1), so the work halves each time.  Lane l
+// (0..15 within the row) ends with the total of value number rwk_halving_index<V>(l); for V = 8 both lanes of a
+// pair hold it.  Fixed order => bitwise reproducible.
+template <int V>
+__device__ static inline int rwk_halving_index(int l) {
+    const int a = l >= 8, b = (l & 7) >= 4, c = (l & 3) >= 2, d = l & 1;
+    return V == 16 ? 8 * a + 4 * b + 2 * c + d : 4 * a + 2 * b + c;
+}
+
+template <int V>
+__device__ static inline float rwk_halving_sum16(const float (&v)[V], int l) {
+    static_assert(V == 8 || V == 16, "8 or 16 values");
+    const bool up_a = l >= 8, up_b = (l & 7) >= 4, up_c = (l & 3) >= 2, up_d = (l & 1) != 0;
+    float a[V / 2], b[V / 4], c[V / 8];
+#pragma unroll
+    for (int m = 0; m < V / 2; ++m) {
+        const float keep = up_a ? v[m + V / 2] : v[m], give = up_a ? v[m] : v[m + V / 2];
+        a[m] = keep + rwk_dpp<0x140>(give);           // row_mirror
+    }
+#pragma unroll
+    for (int m = 0; m < V / 4; ++m) {
+        const float keep = up_b ? a[m + V / 4] : a[m], give = up_b ? a[m] : a[m + V / 4];
+        b[m] = keep + rwk_dpp<0x141>(give);           // row_half_mirror
+    }
+#pragma unroll
+    for (int m = 0; m < V / 8; ++m) {
+        const float keep = up_c ? b[m + V / 8] : b[m], give = up_c ? b[m] : b[m + V / 8];
+        c[m] = keep + rwk_dpp<0x1B>(give);            // quad_perm [3,2,1,0]
+    }
+    if (V == 16) {
+        const float keep = up_d ? c[1] : c[0], give = up_d ? c[0] : c[1];
+        return keep + rwk_dpp<0xB1>(give);            // quad_perm [1,0,3,2]
+    }
+    return c[0] + rwk_dpp<0xB1>(c[0]);
+}
+
 __device__ static inline float rwk_group_sum(float v, int width) {
     if (width >= 2) v += rwk_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
     if (width >= 4) v += rwk_dpp<0x4E>(v);   // quad_perm [2,3,0,1]

@@ -250,6 +250,12 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     for (int i = 0; i < LT; ++i) dp_cur[i] = 0.f;
     int g_cur = -1;
 
+    // where this lane puts its dX total of the halving reduction: float (idx % 4) of row (idx / 4) of slot group0 + j
+    float *red_dst = nullptr;
+    if (HPT == 16 && (LT == 2 || LT == 4)) {
+        const int idx = rwk_halving_index<(LT == 4 ? 16 : 8)>(lane_h);
+        red_dst = reinterpret_cast<float *>(&tile.x[(idx / DP) % LT][group0]) + idx % DP;
+    }
     for (int base = 0; base < stream_len; base += hp) {
         const int my_p = start + base + lane_h;          // the slot this lane loads and later stores
         __syncthreads();
@@ -310,15 +316,24 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                     }
                 }
             }
-            // sum the dX rows over the hidden graphs (the hp lanes of this stream); lane j puts the totals
-            // where the x rows of slot j were: the lanes of a stream share a wavefront, so all of them have
-            // read those rows by now
+            // sum the dX rows over the hidden graphs (the hp lanes of this stream); the totals go where the x
+            // rows of slot j were: the lanes of a stream share a wavefront, so all of them have read those rows
+            if (HPT == 16 && (LT == 2 || LT == 4)) {
+                // halving reduction: lane l ends with the total of value (i, k) = (idx / 4, idx % 4) and stores it
+                constexpr int V = (LT == 2 || LT == 4) ? LT * DP : 8;
+                float vals[V];
 #pragma unroll
-            for (int i = 0; i < LT; ++i) {
-                float tot[DP];
+                for (int e = 0; e < V; ++e) vals[e] = dxr[(e / DP) % LT][e % DP];
+                const float tot = rwk_halving_sum16<V>(vals, lane_h);
+                if (V == 16 || (lane_h & 1) == 0) red_dst[4 * j] = tot;
+            } else {
 #pragma unroll
-                for (int k = 0; k < DP; ++k) tot[k] = rwk_group_sum(dxr[i][k], hp);
-                if (lane_h == j) tile.x[i][group0 + j] = make_float4(tot[0], tot[1], tot[2], tot[3]);
+                for (int i = 0; i < LT; ++i) {
+                    float tot[DP];
+#pragma unroll
+                    for (int k = 0; k < DP; ++k) tot[k] = rwk_group_sum(dxr[i][k], hp);
+                    if (lane_h == j) tile.x[i][group0 + j] = make_float4(tot[0], tot[1], tot[2], tot[3]);
+                }
             }
         }
         if (my_node >= 0) {                               // coalesced: hp lanes store hp consecutive rows
