@@ -15,7 +15,7 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kRows = 32;
+constexpr int kRows = 16;
 constexpr int kMaxBlocks = 256;
 constexpr int kMaxC = 256, kMaxNC = 32, kMaxPC = 4096;
 constexpr uint32_t kHeadCall = 0xFFFFFFFFu;       // Philox counter word no other mask of the model uses
