@@ -416,6 +416,53 @@ head_bwd_finish_kernel(const float *__restrict__ k, HeadDims dm, const float *__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Mean cross-entropy of (G, NC) scores against int64 class labels, as F.cross_entropy with default arguments
+// (rwgnn2/main.py:85 applies it to the model's log-probabilities): loss = mean_r (logsumexp(x_r) - x_r[y_r]).
+// One workgroup, rows strided over its threads, partial sums added in a fixed tree order.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kCeBlock = 1024;
+
+__device__ inline float row_lse(const float *__restrict__ x, int nc) {
+    float mx = x[0];
+    for (int q = 1; q < nc; ++q) mx = fmaxf(mx, x[q]);
+    float se = 0.f;
+    for (int q = 0; q < nc; ++q) se += expf(x[q] - mx);
+    return mx + logf(se);
+}
+
+__global__ void __launch_bounds__(kCeBlock)
+cross_entropy_forward_kernel(const float *__restrict__ x, const long long *__restrict__ y, long long g, int nc,
+                             float *__restrict__ loss) {
+    __shared__ float red[kCeBlock];
+    float acc = 0.f;
+    for (long long r = threadIdx.x; r < g; r += kCeBlock) {
+        const float *row = x + r * nc;
+        long long cls = y[r];
+        cls = cls < 0 ? 0 : (cls >= nc ? nc - 1 : cls);           // labels are validated on the host side
+        acc += row_lse(row, nc) - row[cls];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = kCeBlock / 2; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = red[0] / (float)g;
+}
+
+__global__ void __launch_bounds__(kBlock)
+cross_entropy_backward_kernel(const float *__restrict__ x, const long long *__restrict__ y, long long g, int nc,
+                              const float *__restrict__ d_loss, float *__restrict__ d_x) {
+    const long long r = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= g) return;
+    const float *row = x + r * nc;
+    const float lse = row_lse(row, nc);
+    const float scale = d_loss[0] / (float)g;
+    const long long cls = y[r];
+    for (int q = 0; q < nc; ++q) d_x[r * nc + q] = scale * (expf(row[q] - lse) - (q == cls ? 1.f : 0.f));
+}
+
 size_t fwd_lds(int c, int p, int nc) {
     return sizeof(float) * ((size_t)p * (c + 1) + (size_t)nc * (p + 1) + p + nc + 2 * c + (size_t)kRows * (c + 1) +
                             (size_t)kRows * (p + 1) + (size_t)kRows * nc);
@@ -530,6 +577,32 @@ int rwk_head_backward(const float *k, int64_t g, int64_t c, int64_t p, int64_t n
     RWK_LAUNCH_CHECK();
     hipLaunchKernelGGL(head_bwd_finish_kernel, dim3(blocks), dim3(kBlock), 0, stream, k, dm, bn_w, mean, invstd, dy,
                        partials, blocks, training, grads, d_k);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
+int rwk_cross_entropy_forward(const float *scores, const int64_t *labels, int64_t g, int64_t nc, float *loss,
+                              rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(scores);
+    RWK_REQUIRE_PTR(labels);
+    RWK_REQUIRE_PTR(loss);
+    if (g <= 0 || nc <= 0 || nc > 0x7FFFFFFF) return RWK_E_SIZE;
+    hipLaunchKernelGGL(cross_entropy_forward_kernel, dim3(1), dim3(kCeBlock), 0, (hipStream_t)stream, scores,
+                       (const long long *)labels, (long long)g, (int)nc, loss);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
+int rwk_cross_entropy_backward(const float *scores, const int64_t *labels, int64_t g, int64_t nc,
+                               const float *d_loss, float *d_scores, rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(scores);
+    RWK_REQUIRE_PTR(labels);
+    RWK_REQUIRE_PTR(d_loss);
+    RWK_REQUIRE_PTR(d_scores);
+    if (g <= 0 || nc <= 0 || nc > 0x7FFFFFFF) return RWK_E_SIZE;
+    hipLaunchKernelGGL(cross_entropy_backward_kernel, dim3((unsigned)rwk_ceil_div(g, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, scores, (const long long *)labels, (long long)g, (int)nc, d_loss,
+                       d_scores);
     RWK_LAUNCH_CHECK();
     return RWK_OK;
 }

@@ -15,6 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from .dp import FlatGradBucket
+from .losses import cross_entropy
 from .optim import FlatAdam
 
 __all__ = ["Trainer"]
@@ -24,11 +25,13 @@ class Trainer:
     """One model, one resident batch ``(adj, features, graph_indicator, y)``.
 
     ``world`` > 1: the flat gradient bucket is all-reduced (mean) over the default process group between the
-    backward and the optimiser step.  ``optimizer``: "flat" (``gnn_amd.optim.FlatAdam``, same arithmetic as
+    backward and the optimiser step.  ``fused_loss``: ``gnn_amd.losses.cross_entropy`` (same value and gradient
+    as ``F.cross_entropy``, two launches instead of torch's eight).  ``optimizer``: "flat" (``gnn_amd.optim.FlatAdam``, same arithmetic as
     ``torch.optim.Adam``, one launch) or "torch" (``torch.optim.Adam(capturable=True)``).
     """
 
-    def __init__(self, model, batch_t, world: int = 1, optimizer: str = "flat", lr: float = 1e-2):
+    def __init__(self, model, batch_t, world: int = 1, optimizer: str = "flat", lr: float = 1e-2,
+                 fused_loss: bool = True):
         self.model = model
         self.adj, self.feats, self.gi, self.y = batch_t
         self.bucket = FlatGradBucket(model)
@@ -37,6 +40,8 @@ class Trainer:
             self.opt = FlatAdam(model, self.bucket, lr=lr)
         else:
             self.opt = torch.optim.Adam(model.parameters(), lr=lr, capturable=True, foreach=True)
+        # F.cross_entropy(output, y) of main.py:85, one launch each way (gnn_amd.losses) or torch's own kernels
+        self.loss_fn = cross_entropy if fused_loss else F.cross_entropy
         self.loss = None
         self.g_fb = None
         self.g_opt = None
@@ -44,7 +49,7 @@ class Trainer:
     def fwd_bwd(self):
         self.bucket.release()            # optimizer.zero_grad(set_to_none=True)
         out = self.model(self.adj, self.feats, self.gi)
-        self.loss = F.cross_entropy(out, self.y)
+        self.loss = self.loss_fn(out, self.y)
         self.loss.backward()
         self.bucket.gather()             # per-parameter gradients -> the flat bucket, one launch
 

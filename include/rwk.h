@@ -227,6 +227,15 @@ int rwk_head_backward(const float *k, int64_t g, int64_t c, int64_t p, int64_t n
                       const float *d_out, float drop_p, float *dy, float *partials, float *grads,
                       float *d_k, rwk_stream_t stream);
 
+/* Mean cross-entropy of (g, nc) scores against int64 labels in [0, nc): F.cross_entropy with its
+ * default arguments, as rwgnn2/main.py:85,92 applies it to the model's output.  loss: device
+ * float[1].  Backward: d_scores = d_loss[0] / g * (softmax(scores) - onehot(labels)).
+ * One launch each way (torch: six). */
+int rwk_cross_entropy_forward(const float *scores, const int64_t *labels, int64_t g, int64_t nc,
+                              float *loss, rwk_stream_t stream);
+int rwk_cross_entropy_backward(const float *scores, const int64_t *labels, int64_t g, int64_t nc,
+                               const float *d_loss, float *d_scores, rwk_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Input projection  X0 = sigmoid(features W^T + b)   replaces model.py:43 for narrow inputs
  * (input_dim <= 8; wider inputs go through a GEMM library and only the sigmoid is applied here)

@@ -126,3 +126,23 @@ def test_graph_replay_draws_fresh_dropout_masks(dev):
     # two masks per step: the random-walk layer's and the head's, one generator offset each
     assert offsets == list(range(offsets[0], offsets[0] + 10, 2))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0] + 0.2
+
+
+def test_fused_cross_entropy_matches_torch(dev):
+    """gnn_amd.losses.cross_entropy against F.cross_entropy in float64 (value and gradient), on log-probabilities
+    as main.py:85 feeds it and on raw scores."""
+    from gnn_amd.losses import cross_entropy
+    rng = np.random.default_rng(9)
+    for g, nc, logp in ((1024, 2, True), (7, 5, False), (5000, 10, True), (1, 3, False)):
+        x = rng.normal(size=(g, nc)).astype(np.float32) * 3
+        if logp:
+            x = (torch.log_softmax(torch.from_numpy(x), dim=1)).numpy()
+        y = rng.integers(0, nc, size=g)
+        x64 = torch.from_numpy(x).double().requires_grad_(True)
+        ref = F.cross_entropy(x64, torch.from_numpy(y))
+        (ref * 1.7).backward()
+        xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+        got = cross_entropy(xd, torch.from_numpy(y).to(dev))
+        (got * 1.7).backward()
+        assert got.shape == () and abs(float(got) - float(ref)) <= 1e-5 * max(abs(float(ref)), 1e-3)
+        assert rel_err(xd.grad.cpu().numpy(), x64.grad.numpy()) < 1e-5
