@@ -20,6 +20,40 @@ constexpr int DP = 4;
 // 4 (<= 128 VGPRs, four 256-thread workgroups per CU) up to L*S = 10, then 2, then 1.
 constexpr int bwd_waves_per_simd(int ls) { return ls <= 10 ? 3 : (ls <= 20 ? 2 : 1); }
 
+// Diagnostic build only (-DRWK_STAMP): cycle shares of the backward kernel's segments for the wavefronts of one
+// workgroup; slot 7 holds the wavefront's lifetime in 100 MHz ticks.
+#ifdef RWK_STAMP
+__device__ unsigned long long rwk_reg_stamp_buf[4 * 8];
+__device__ unsigned long long rwk_reg_stamp_blocks[2 * 2048];   // start / end of each workgroup, 100 MHz ticks
+#define RWK_STAMP_DECL()                                                              \
+    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};                          \
+    unsigned long long st_last = __builtin_readcyclecounter();                        \
+    const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime()
+#define RWK_STAMP_AT(k)                                                      \
+    do {                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+        const unsigned long long now_ = __builtin_readcyclecounter();        \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+        st_sum[k] += now_ - st_last;                                         \
+        st_last = now_;                                                      \
+    } while (0)
+#define RWK_STAMP_FLUSH()                                                    \
+    do {                                                                     \
+        const unsigned long long rt1_ = __builtin_amdgcn_s_memrealtime();    \
+        st_sum[7] = rt1_ - st_rt0;                                           \
+        if (threadIdx.x == 0 && blockIdx.x < 2048) {                         \
+            rwk_reg_stamp_blocks[2 * blockIdx.x] = st_rt0;                   \
+            rwk_reg_stamp_blocks[2 * blockIdx.x + 1] = rt1_;                 \
+        }                                                                    \
+        if (blockIdx.x == 300 && (threadIdx.x & 63) == 0)                    \
+            for (int k_ = 0; k_ < 8; ++k_) rwk_reg_stamp_buf[(threadIdx.x >> 6) * 8 + k_] = st_sum[k_]; \
+    } while (0)
+#else
+#define RWK_STAMP_DECL()
+#define RWK_STAMP_AT(k)
+#define RWK_STAMP_FLUSH()
+#endif
+
 struct DropCfg {
     uint32_t t0, t1, seed_lo, key_hi, off_lo;
 };
@@ -225,6 +259,7 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     __shared__ Tile<LT> tile;
     __shared__ float red[CH][kBlock];
 
+    RWK_STAMP_DECL();
     const int tid = threadIdx.x;
     const int lane_h = tid % hp;
     const int hh = lane_h < h ? lane_h : h - 1;
@@ -258,10 +293,12 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     }
     for (int base = 0; base < stream_len; base += hp) {
         const int my_p = start + base + lane_h;          // the slot this lane loads and later stores
+        RWK_STAMP_AT(0);
         __syncthreads();
         load_tile<LT>(tile, x, gid, perm, my_p, end, has_stream, d, step_stride);
         __syncthreads();
         const int my_node = tile.node[tid];
+        RWK_STAMP_AT(1);
         // every lane of the wavefront runs all hp iterations: the DPP butterfly needs them all
         const int jmax = stream_len - base < hp ? stream_len - base : hp;
         for (int j = 0; j < jmax; ++j) {
@@ -336,6 +373,7 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                 }
             }
         }
+        RWK_STAMP_AT(2);
         if (my_node >= 0) {                               // coalesced: hp lanes store hp consecutive rows
 #pragma unroll
             for (int i = 0; i < LT; ++i) {
@@ -353,6 +391,7 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
         }
     }
 
+    RWK_STAMP_AT(3);
     // per-workgroup partial of dZ: threads that own the same hidden graph are added in thread order
     const int spb = kBlock / hp;
     float *out = dz_partials + (size_t)blockIdx.x * LT * h * ST * d;
@@ -374,6 +413,8 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
             out[(((size_t)i * h + hq) * ST + ss) * d + k] = acc;
         }
     }
+    RWK_STAMP_AT(4);
+    RWK_STAMP_FLUSH();
 }
 
 inline int pow2_ceil(int v) {
@@ -459,6 +500,15 @@ int64_t stream_len(int64_t n, int64_t h, int64_t s, int64_t max_step, bool bwd) 
     const int64_t len = rwk_ceil_div(n, per_round * m);
     return len < 8 ? 8 : len;
 }
+
+#ifdef RWK_STAMP
+extern "C" int rwk_debug_read_reg_stamps(unsigned long long *host32) {
+    return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(rwk_reg_stamp_buf), sizeof(unsigned long long) * 32);
+}
+extern "C" int rwk_debug_read_reg_blocks(unsigned long long *host4096) {
+    return (int)hipMemcpyFromSymbol(host4096, HIP_SYMBOL(rwk_reg_stamp_blocks), sizeof(unsigned long long) * 4096);
+}
+#endif
 
 int forward(const Args &a) { return by_l(a, false); }
 int backward(const Args &a) { return by_l(a, true); }
