@@ -178,6 +178,12 @@ def time_kernels(batch_t, hp, budget_ms=150.0, only=None):
                      "GB/s": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4), "TFLOP/s": round(tfs, 3),
                      "frac_fp32_peak": round(tfs / FP32_PEAK_TFLOPS, 4), "bound": bound[name],
                      "flop_per_byte": round(flops[name] / bytes_[name], 1), "executes_on": unit_of[name]}
+        if name == "spmm_csr":
+            # the compact structure (16-bit column distances, no value array for unweighted graphs) moves fewer
+            # bytes than the algorithmic count, which is defined on int32 columns and fp32 values
+            moved = st.spmm_bytes_moved(d)
+            out[name]["bytes_moved"] = int(moved)
+            out[name]["GB/s_moved"] = round(moved / (us * 1e-6) / 1e9, 1)
     out["_shape"] = {"nodes": n, "nnz": st.nnz, "graphs": g, "stream_len": [stream_len, stream_len_b],
                      "fused_path": {0: "generic", 1: "register", 2: "mfma"}[path]}
     return out

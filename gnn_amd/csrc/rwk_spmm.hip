@@ -88,20 +88,27 @@ spmm_csr_kernel(const int32_t *__restrict__ crow, const int32_t *__restrict__ co
 // from LDS in stored order (an fmaf chain, as a sequential CSR loop would).  Rows with more than
 // kLongRow entries in the tile (power-law hubs) are summed by the whole workgroup instead, in a fixed
 // tree order.  y is written coalesced, one 16-byte chunk per lane.
-// ---------------------------------------------------------------------------------------------------
 constexpr int kTileBytes = 16 * 1024;
 constexpr int kLongRow = 64;
 
-template <int VEC, bool ALIGNED>
+//
+// Compact structure (COLT = int16_t): a column is stored as its distance from the first row of the 256-row
+// block its row lies in (block-diagonal batches of graphs below 32 k nodes fit 16 bits), and UNIT says that
+// every stored value is exactly 1.0f (unweighted graphs), so no value array is read: 2 bytes per stored entry
+// instead of 8.  acc + t is what fmaf(1.0f, t, acc) returns, so the results are the same bits.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kColBlock = 256;
+
+template <int VEC, bool ALIGNED, typename COLT, bool UNIT>
 __global__ void __launch_bounds__(kBlock)
-spmm_tile_kernel(const int32_t *__restrict__ crow, const int32_t *__restrict__ col, const float *__restrict__ val,
+spmm_tile_kernel(const int32_t *__restrict__ crow, const COLT *__restrict__ col, const float *__restrict__ val,
                  int n, int d, const float *__restrict__ x, float *__restrict__ y, int accumulate) {
     constexpr int RPW = kBlock / VEC;                   // rows per workgroup = entry slots per pass
     constexpr int ET = kTileBytes / (16 * VEC);         // entries per LDS tile
     constexpr int PASSES = ET / RPW;
     constexpr int GP = PASSES < 4 ? PASSES : 4;         // passes whose loads are issued together
     __shared__ float4 s_x[ET * VEC];
-    __shared__ float s_val[ET];
+    __shared__ float s_val[UNIT ? 1 : ET];
     __shared__ float4 s_red[kBlock];
     __shared__ int s_crow[RPW + 1];
     __shared__ int s_long[RPW];
@@ -116,6 +123,7 @@ spmm_tile_kernel(const int32_t *__restrict__ crow, const int32_t *__restrict__ c
     const int lb = (int)blockIdx.x < per_xcd * 8 ? ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8
                                                  : (int)blockIdx.x;
     const int r0 = lb * RPW;
+    const int col_base = sizeof(COLT) == 2 ? (r0 & ~(kColBlock - 1)) : 0;
     const int nrows = n - r0 < RPW ? n - r0 : RPW;
     for (int i = tid; i <= nrows; i += kBlock) s_crow[i] = crow[r0 + i];
     if (tid == 0) s_nlong = 0;
@@ -139,8 +147,8 @@ spmm_tile_kernel(const int32_t *__restrict__ crow, const int32_t *__restrict__ c
             for (int k = 0; k < GP; ++k) {
                 const int e = cb + slot + (g + k) * RPW;
                 const int ec = e < ce ? e : ce - 1;
-                c[k] = col[ec];
-                v[k] = val[ec];
+                c[k] = (int)col[ec] + col_base;
+                v[k] = UNIT ? 1.f : val[ec];
             }
             float4 xv[GP];
 #pragma unroll
@@ -164,7 +172,7 @@ spmm_tile_kernel(const int32_t *__restrict__ crow, const int32_t *__restrict__ c
                 const int e = cb + slot + (g + k) * RPW;
                 if (e < ce) {
                     s_x[(e - cb) * VEC + sub] = xv[k];
-                    if (sub == 0) s_val[e - cb] = v[k];
+                    if (!UNIT && sub == 0) s_val[e - cb] = v[k];
                 }
             }
         }
@@ -175,12 +183,16 @@ spmm_tile_kernel(const int32_t *__restrict__ crow, const int32_t *__restrict__ c
         const bool is_long = hi - lo > kLongRow;
         if (!is_long) {
             for (int e = lo; e < hi; ++e) {
-                const float w = s_val[e - cb];
                 const float4 t = s_x[(e - cb) * VEC + sub];
-                acc.x = fmaf(w, t.x, acc.x);
-                acc.y = fmaf(w, t.y, acc.y);
-                acc.z = fmaf(w, t.z, acc.z);
-                acc.w = fmaf(w, t.w, acc.w);
+                if (UNIT) {
+                    acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+                } else {
+                    const float w = s_val[e - cb];
+                    acc.x = fmaf(w, t.x, acc.x);
+                    acc.y = fmaf(w, t.y, acc.y);
+                    acc.z = fmaf(w, t.z, acc.z);
+                    acc.w = fmaf(w, t.w, acc.w);
+                }
             }
         } else if (sub == 0) {
             s_long[atomicAdd(&s_nlong, 1)] = slot;       // LDS counter; the order of the list does not matter
@@ -193,7 +205,7 @@ spmm_tile_kernel(const int32_t *__restrict__ crow, const int32_t *__restrict__ c
             const int hi_k = s_crow[rs + 1] < ce ? s_crow[rs + 1] : ce;
             float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int e = lo_k + slot; e < hi_k; e += RPW) {
-                const float w = s_val[e - cb];
+                const float w = UNIT ? 1.f : s_val[e - cb];
                 const float4 t = s_x[(e - cb) * VEC + sub];
                 part.x = fmaf(w, t.x, part.x);
                 part.y = fmaf(w, t.y, part.y);
@@ -238,19 +250,48 @@ spmm_tile_kernel(const int32_t *__restrict__ crow, const int32_t *__restrict__ c
     }
 }
 
-template <int VEC>
-int launch_tile(const int32_t *crow, const int32_t *col, const float *val, int64_t n, int64_t d, const float *x,
+template <int VEC, typename COLT>
+int launch_tile(const int32_t *crow, const COLT *col, const float *val, int64_t n, int64_t d, const float *x,
                 float *y, int accumulate, hipStream_t stream) {
     const bool aligned = (d == 4 * VEC) && ((((uintptr_t)x | (uintptr_t)y) & 15u) == 0);
     const dim3 grid((unsigned)rwk_ceil_div(n, kBlock / VEC));
-    if (aligned)
-        hipLaunchKernelGGL((spmm_tile_kernel<VEC, true>), grid, dim3(kBlock), 0, stream, crow, col, val, (int)n, (int)d,
-                           x, y, accumulate);
-    else
-        hipLaunchKernelGGL((spmm_tile_kernel<VEC, false>), grid, dim3(kBlock), 0, stream, crow, col, val, (int)n,
-                           (int)d, x, y, accumulate);
+#define RWK_TILE(AL, UN)                                                                                        \
+    hipLaunchKernelGGL((spmm_tile_kernel<VEC, AL, COLT, UN>), grid, dim3(kBlock), 0, stream, crow, col, val, (int)n, \
+                       (int)d, x, y, accumulate)
+    if (val == nullptr) { if (aligned) RWK_TILE(true, true); else RWK_TILE(false, true); }
+    else { if (aligned) RWK_TILE(true, false); else RWK_TILE(false, false); }
+#undef RWK_TILE
     RWK_LAUNCH_CHECK();
     return RWK_OK;
+}
+
+template <typename COLT>
+int launch_tile_by_width(const int32_t *crow, const COLT *col, const float *val, int64_t n, int64_t d, const float *x,
+                         float *y, int accumulate, hipStream_t stream) {
+    const int vec = (int)((d + 3) / 4);
+    if (vec == 1) return launch_tile<1, COLT>(crow, col, val, n, d, x, y, accumulate, stream);
+    if (vec == 2) return launch_tile<2, COLT>(crow, col, val, n, d, x, y, accumulate, stream);
+    if (vec <= 4) return launch_tile<4, COLT>(crow, col, val, n, d, x, y, accumulate, stream);
+    if (vec <= 8) return launch_tile<8, COLT>(crow, col, val, n, d, x, y, accumulate, stream);
+    return launch_tile<16, COLT>(crow, col, val, n, d, x, y, accumulate, stream);
+}
+
+// col16[e] = col[e] - (row & ~255); flags[0] counts entries that do not fit, flags[1] values other than 1.0f
+__global__ void __launch_bounds__(kBlock)
+csr_compact_kernel(const int32_t *__restrict__ crow, const int32_t *__restrict__ col, const float *__restrict__ val,
+                   int n, int16_t *__restrict__ col16, int32_t *__restrict__ flags) {
+    const int row = blockIdx.x * kBlock + threadIdx.x;
+    if (row >= n) return;
+    const int base = row & ~(kColBlock - 1);
+    int bad = 0, weighted = 0;
+    for (int e = crow[row]; e < crow[row + 1]; ++e) {
+        const int dlt = col[e] - base;
+        if (dlt < -32768 || dlt > 32767) ++bad;
+        col16[e] = (int16_t)dlt;
+        if (val[e] != 1.0f) ++weighted;
+    }
+    if (bad) atomicAdd(&flags[0], bad);
+    if (weighted) atomicAdd(&flags[1], weighted);
 }
 
 template <int VEC>
@@ -302,15 +343,36 @@ extern "C" int rwk_spmm_csr(const int32_t *crow, const int32_t *col, const float
     hipStream_t stream = (hipStream_t)stream_;
     const int vec = (int)((d + 3) / 4);
     if (row_lanes == 0) {                               // sparse rows: the tile kernel (hubs handled inside)
-        if (vec == 1) return launch_tile<1>(crow, col, val, n, d, x, y, accumulate, stream);
-        if (vec == 2) return launch_tile<2>(crow, col, val, n, d, x, y, accumulate, stream);
-        if (vec <= 4) return launch_tile<4>(crow, col, val, n, d, x, y, accumulate, stream);
-        if (vec <= 8) return launch_tile<8>(crow, col, val, n, d, x, y, accumulate, stream);
-        return launch_tile<16>(crow, col, val, n, d, x, y, accumulate, stream);
+        return launch_tile_by_width<int32_t>(crow, col, val, n, d, x, y, accumulate, stream);
     }
     if (vec == 1) return launch<1>(crow, col, val, n, d, x, y, accumulate, row_lanes, long_rows, n_long, long_threshold, stream);
     if (vec == 2) return launch<2>(crow, col, val, n, d, x, y, accumulate, row_lanes, long_rows, n_long, long_threshold, stream);
     if (vec <= 4) return launch<4>(crow, col, val, n, d, x, y, accumulate, row_lanes, long_rows, n_long, long_threshold, stream);
     if (vec <= 8) return launch<8>(crow, col, val, n, d, x, y, accumulate, row_lanes, long_rows, n_long, long_threshold, stream);
     return launch<16>(crow, col, val, n, d, x, y, accumulate, row_lanes, long_rows, n_long, long_threshold, stream);
+}
+
+extern "C" int rwk_csr_compact(const int32_t *crow, const int32_t *col, const float *val, int64_t n, int16_t *col16,
+                               int32_t *flags, rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(crow);
+    RWK_REQUIRE_PTR(col);
+    RWK_REQUIRE_PTR(val);
+    RWK_REQUIRE_PTR(col16);
+    RWK_REQUIRE_PTR(flags);
+    if (n <= 0 || n >= 0x7FFFFFFFll) return RWK_E_SIZE;
+    hipLaunchKernelGGL(csr_compact_kernel, dim3((unsigned)rwk_ceil_div(n, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, crow, col, val, (int)n, col16, flags);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
+extern "C" int rwk_spmm_csr_compact(const int32_t *crow, const int16_t *col16, const float *val, int64_t n, int64_t d,
+                                    const float *x, float *y, int accumulate, rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(crow);
+    RWK_REQUIRE_PTR(col16);
+    RWK_REQUIRE_PTR(x);
+    RWK_REQUIRE_PTR(y);
+    if (n <= 0 || n >= 0x7FFFFFFFll || d <= 0) return RWK_E_SIZE;
+    if (d > 64) return RWK_E_UNSUPPORTED;
+    return launch_tile_by_width<int16_t>(crow, col16, val, n, d, x, y, accumulate, (hipStream_t)stream);
 }

@@ -21,10 +21,13 @@ __all__ = ["GraphStructure", "get_structure", "clear_structure_cache", "spmm_sch
 
 
 class _Csr:
-    __slots__ = ("crow", "col", "val", "row_lanes", "long_rows", "long_threshold", "max_degree")
+    __slots__ = ("crow", "col", "val", "row_lanes", "long_rows", "long_threshold", "max_degree", "col16",
+                 "unit_values")
 
     def __init__(self, crow, col, val):
         self.crow, self.col, self.val = crow, col, val
+        self.col16 = None          # int16 column distances for the tile kernel, when they all fit
+        self.unit_values = False   # every stored value is exactly 1.0
         self.row_lanes = 1
         self.long_rows = None
         self.long_threshold = 0
@@ -186,10 +189,21 @@ class GraphStructure:
         _lib.check(lib.rwk_csr_from_sorted_coo(_lib.ptr(rows), _lib.ptr(cols), _lib.ptr(vals), nnz, n,
                                                crow.data_ptr(), col.data_ptr(), val.data_ptr(), stream),
                    "rwk_csr_from_sorted_coo")
-        return _Csr(crow, col, val)
+        csr = _Csr(crow, col, val)
+        if nnz:
+            csr.col16 = torch.empty(nnz, dtype=torch.int16, device=dev)
+            csr.unit_values = torch.zeros(2, dtype=torch.int32, device=dev)      # flags until _schedule reads them
+            _lib.check(lib.rwk_csr_compact(crow.data_ptr(), col.data_ptr(), val.data_ptr(), n, csr.col16.data_ptr(),
+                                           csr.unit_values.data_ptr(), stream), "rwk_csr_compact")
+        return csr
 
     def _schedule(self, csr: _Csr, max_degree: int):
         csr.max_degree = int(max_degree)
+        if torch.is_tensor(csr.unit_values):
+            too_far, weighted = csr.unit_values.cpu().tolist()
+            if too_far:
+                csr.col16 = None
+            csr.unit_values = weighted == 0
         csr.row_lanes, csr.long_threshold = spmm_schedule(self.n, self.nnz, csr.max_degree)
         if csr.long_threshold:
             deg = csr.crow[1:] - csr.crow[:-1]
@@ -199,10 +213,18 @@ class GraphStructure:
     def spmm(self, x: torch.Tensor, y: torch.Tensor, transpose: bool = False, accumulate: bool = False,
              kernel: Optional[str] = None):
         """y = A x (or A^T x), optionally accumulated into y.  x, y: contiguous (N, D) float32.
-        ``kernel``: "tile" or "packed" to force a schedule (tests); default: the degree-histogram rule."""
+        ``kernel``: "tile", "tile32" (tile kernel on the int32 columns and the value array) or "packed" to force
+        a schedule (tests); default: the degree-histogram rule, compact structure when it exists."""
         lib = _lib.load()
         csr = self.csr_t if transpose else self.csr
-        tile = use_tile_kernel(self.n, self.nnz, csr.max_degree, x.shape[1]) if kernel is None else kernel == "tile"
+        tile = use_tile_kernel(self.n, self.nnz, csr.max_degree, x.shape[1]) if kernel is None \
+            else kernel in ("tile", "tile32")
+        if tile and csr.col16 is not None and kernel != "tile32":
+            _lib.check(lib.rwk_spmm_csr_compact(csr.crow.data_ptr(), csr.col16.data_ptr(),
+                                                None if csr.unit_values else csr.val.data_ptr(), self.n, x.shape[1],
+                                                x.data_ptr(), y.data_ptr(), int(accumulate),
+                                                _lib.current_stream(self.device)), "rwk_spmm_csr_compact")
+            return
         n_long = 0 if (tile or csr.long_rows is None) else csr.long_rows.numel()
         _lib.check(lib.rwk_spmm_csr(csr.crow.data_ptr(), _lib.ptr(csr.col), _lib.ptr(csr.val), self.n,
                                     x.shape[1], x.data_ptr(), y.data_ptr(), int(accumulate),
@@ -213,6 +235,15 @@ class GraphStructure:
     def spmm_bytes(self, d: int) -> int:
         """Algorithmic HBM bytes of one SpMM launch: values + columns + row pointers + x + y."""
         return self.nnz * 8 + (self.n + 1) * 4 + 2 * self.n * d * 4
+
+    def spmm_bytes_moved(self, d: int, transpose: bool = False) -> int:
+        """Bytes the scheduled kernel reads and writes: as :meth:`spmm_bytes`, with 2 bytes per stored entry for
+        16-bit column distances and none for values that are all 1.0 when the tile kernel runs on them."""
+        csr = self.csr_t if transpose else self.csr
+        per_entry = 8
+        if csr.col16 is not None and use_tile_kernel(self.n, self.nnz, csr.max_degree, d):
+            per_entry = 2 + (0 if csr.unit_values else 4)
+        return self.nnz * per_entry + (self.n + 1) * 4 + 2 * self.n * d * 4
 
 
 # ----------------------------------------------------------------------------------------

@@ -114,6 +114,18 @@ int rwk_spmm_csr(const int32_t *crow, const int32_t *col, const float *val, int6
                  const int32_t *long_rows, int64_t n_long, int32_t long_threshold,
                  rwk_stream_t stream);
 
+/* Compact structure for the tile kernel (same product, same bits; model.py:55 on the block-diagonal,
+ * unweighted batches that rwgnn2/utils.py:47-85 builds).  rwk_csr_compact writes col16[e] = col[e] minus the
+ * first row of the 256-row block that e's row lies in, as int16 (nnz of them), and adds to flags[0] the number
+ * of entries whose distance does not fit 16 bits and to flags[1] the number of stored values other than 1.0f
+ * (flags: int32[2], zeroed by the caller).  When flags[0] == 0, rwk_spmm_csr_compact computes y = A x (+ y) with
+ * the tile kernel from (crow, col16); val == NULL declares every stored value to be 1.0f (allowed when
+ * flags[1] == 0): 2 bytes per stored entry are read instead of 8. */
+int rwk_csr_compact(const int32_t *crow, const int32_t *col, const float *val, int64_t n, int16_t *col16,
+                    int32_t *flags, rwk_stream_t stream);
+int rwk_spmm_csr_compact(const int32_t *crow, const int16_t *col16, const float *val, int64_t n, int64_t d,
+                         const float *x, float *y, int accumulate, rwk_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * (2) hidden graphs   Ah = sym(triu(relu(adj_hidden))),  Z[i] = Ah Z[i-1]
  *     replaces model.py:39-42 and :56 for all steps in one launch.

@@ -246,9 +246,12 @@ def test_spmm_directed_and_long_rows(dev):
         ax = O.csr_matmul(crow, col, val, x.astype(np.float64))
         atx = O.csr_matmul(t_crow, t_col, t_val, x.astype(np.float64))
         y0 = torch.from_numpy(rng.uniform(-1, 1, size=(n, d)).astype(np.float32)).to(dev)
-        for kernel in ("packed", "tile", None):
+        assert st.csr.col16 is not None and not st.csr.unit_values      # 6001 rows: every distance fits 16 bits
+        results = {}
+        for kernel in ("packed", "tile", "tile32", None):
             y = torch.full_like(xd, float("nan"))
             st.spmm(xd, y, kernel=kernel)
+            results[kernel] = y
             assert rel_err(y.cpu().numpy(), ax) < TOL, (d, kernel)
             y1 = y0.clone()
             st.spmm(xd, y1, transpose=True, accumulate=True, kernel=kernel)
@@ -256,6 +259,50 @@ def test_spmm_directed_and_long_rows(dev):
             y2 = torch.full_like(xd, float("nan"))
             st.spmm(xd, y2, kernel=kernel)
             assert torch.equal(y, y2), "SpMM must be bitwise reproducible"
+        assert torch.equal(results["tile"], results["tile32"]), "16-bit column distances must not change a bit"
+
+
+def test_spmm_compact_structure(dev):
+    """The compact structure of the tile kernel: unweighted block-diagonal batches get 16-bit column distances and
+    no value array (bit-identical to the int32 / fp32 structure); a column further than 32767 rows away, or a
+    weight, switches the respective part off."""
+    from gnn_amd import GraphStructure
+    rng = np.random.default_rng(11)
+    n = 70000
+
+    def build(r, c, v):
+        key = np.unique(r.astype(np.int64) * n + c)
+        r, c = key // n, key % n
+        adj = torch.sparse_coo_tensor(torch.from_numpy(np.vstack([r, c])), torch.from_numpy(v[:r.size].copy()),
+                                      (n, n)).to(dev)
+        return GraphStructure.build(adj, torch.zeros(n, dtype=torch.int64, device=dev)), (r, c, v[:r.size])
+
+    # near-diagonal, unweighted, directed: columns within +-3000 of the row, including rows near block edges
+    r = rng.integers(0, n, size=250000)
+    c = np.clip(r + rng.integers(-3000, 3001, size=r.size), 0, n - 1)
+    st, (r1, c1, v1) = build(r, c, np.ones(r.size, dtype=np.float32))
+    assert st.csr.col16 is not None and st.csr.unit_values and st.csr_t.col16 is not None
+    crow, col, val = O.coo_to_csr(np.vstack([r1, c1]), v1, n)
+    for d in (4, 6, 16):
+        x = rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
+        xd = torch.from_numpy(x).to(dev)
+        ya, yb = torch.empty_like(xd), torch.empty_like(xd)
+        st.spmm(xd, ya, kernel="tile")
+        st.spmm(xd, yb, kernel="tile32")
+        assert torch.equal(ya, yb)
+        assert rel_err(ya.cpu().numpy(), O.csr_matmul(crow, col, val, x.astype(np.float64))) < TOL
+        assert st.spmm_bytes_moved(d) == st.nnz * 2 + (n + 1) * 4 + 2 * n * d * 4
+    # weights: 16-bit distances stay, the value array is read
+    st_w, _ = build(r, c, rng.uniform(0.5, 1.5, size=r.size).astype(np.float32))
+    assert st_w.csr.col16 is not None and not st_w.csr.unit_values
+    # one far column: back to int32 columns
+    st_f, _ = build(np.append(r, 5), np.append(c, 60000), np.ones(r.size + 1, dtype=np.float32))
+    assert st_f.csr.col16 is None
+    xd = torch.rand((n, 4), device=dev)
+    ya, yb = torch.empty_like(xd), torch.empty_like(xd)
+    st_f.spmm(xd, ya)
+    st_f.spmm(xd, yb, kernel="tile32")
+    assert torch.equal(ya, yb)
 
 
 def test_error_behaviour(dev):
