@@ -99,12 +99,33 @@ __device__ inline void chan_merge(float &n, float &mean, float &m2, float nb, fl
 // Batch statistics of one column from the per-block partials, computed by 8 cooperating lanes (lane8 = 0..7 of
 // an aligned group): lane l merges blocks l, l+8, ... in order, then the eight results are merged pairwise, the
 // lower lane's value always on the left, so that every lane (and every workgroup) ends with the same bits.
+// The partials are fetched eight blocks at a time (24 loads in flight), then merged: a load per merge step would
+// cost a round trip to L2 each.
+struct StatsChunk {
+    float n[8], mean[8], m2[8];
+    __device__ inline void load(const float *__restrict__ partials, int n_blocks, int c, int col, int b0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int b = b0 + 8 * u;
+            const float *p = partials + (size_t)(b < n_blocks ? b : n_blocks - 1) * (1 + 2 * c);
+            n[u] = p[0];
+            mean[u] = p[1 + col];
+            m2[u] = p[1 + c + col];
+            if (b >= n_blocks) n[u] = 0.f;                // merged as an empty block
+        }
+    }
+};
+
 __device__ inline float merge_stats8(const float *__restrict__ partials, int n_blocks, int c, int col, int lane8,
-                                     float *var) {
+                                     StatsChunk &first, float *var) {
     float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int b = lane8; b < n_blocks; b += 8) {
-        const float *p = partials + (size_t)b * (1 + 2 * c);
-        chan_merge(n, mean, m2, p[0], p[1 + col], p[1 + c + col]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) chan_merge(n, mean, m2, first.n[u], first.mean[u], first.m2[u]);
+    for (int b0 = lane8 + 64; b0 < n_blocks; b0 += 64) {
+        StatsChunk next;
+        next.load(partials, n_blocks, c, col, b0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) chan_merge(n, mean, m2, next.n[u], next.mean[u], next.m2[u]);
     }
 #pragma unroll
     for (int off = 1; off < 8; off <<= 1) {
@@ -117,6 +138,29 @@ __device__ inline float merge_stats8(const float *__restrict__ partials, int n_b
     *var = n > 0.f ? m2 / n : 0.f;
     return mean;
 }
+
+// The first kBlock * U elements of a parameter array, fetched into registers so that the loads of several arrays
+// are in flight together before the first of them is stored to LDS.
+template <int U>
+struct ParamChunk {
+    float v[U];
+    __device__ inline void load(const float *__restrict__ src, int n, int tid) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = tid + u * kBlock;
+            v[u] = src[i < n ? i : n - 1];
+        }
+    }
+    // dst[(i / w) * ws + i % w] = src[i]; elements beyond the chunk are copied by a plain loop
+    __device__ inline void store_rows(const float *__restrict__ src, int n, int w, int ws, float *dst, int tid) const {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = tid + u * kBlock;
+            if (i < n) dst[(i / w) * ws + i % w] = v[u];
+        }
+        for (int i = tid + U * kBlock; i < n; i += kBlock) dst[(i / w) * ws + i % w] = src[i];
+    }
+};
 
 struct HeadDims {
     long long g;
@@ -148,38 +192,48 @@ head_apply_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
     float *s_o = s_h + kRows * ps;           // [kRows][nc]
     const int tid = threadIdx.x;
 
-    for (int i = tid; i < p * c; i += kBlock) s_w1[(i / c) * cs + i % c] = w1[i];
-    for (int i = tid; i < nc * p; i += kBlock) s_w2[(i / p) * ps + i % p] = w2[i];
-    for (int i = tid; i < p; i += kBlock) s_b1[i] = b1[i];
-    for (int i = tid; i < nc; i += kBlock) s_b2[i] = b2[i];
+    // all parameter loads and the first chunk of batch-statistics partials in flight together
+    ParamChunk<4> r_w1;
+    ParamChunk<1> r_w2, r_b1, r_b2;
+    r_w1.load(w1, p * c, tid);
+    r_w2.load(w2, nc * p, tid);
+    r_b1.load(b1, p, tid);
+    r_b2.load(b2, nc, tid);
     const int lane8 = tid & 7;
-    for (int c0 = 0; c0 < c; c0 += kBlock / 8) {             // uniform trip count: the shuffles need all lanes
+    int c0 = 0;
+    do {                                                      // uniform trip count: the shuffles need all lanes
         const int col_raw = c0 + (tid >> 3);
         const int col = col_raw < c ? col_raw : c - 1;
-        float mean, var;
-        if (training) {
-            mean = merge_stats8(partials, n_partials, c, col, lane8, &var);
-        } else {
-            mean = running_mean[col];
-            var = running_var[col];
+        StatsChunk first;
+        if (training) first.load(partials, n_partials, c, col, lane8);
+        const float rm = running_mean[col], rv = running_var[col], ga = bn_w[col], be = bn_b[col];
+        if (c0 == 0) {
+            r_w1.store_rows(w1, p * c, c, cs, s_w1, tid);
+            r_w2.store_rows(w2, nc * p, p, ps, s_w2, tid);
+            r_b1.store_rows(b1, p, p, p, s_b1, tid);
+            r_b2.store_rows(b2, nc, nc, nc, s_b2, tid);
         }
-        if (lane8 != 0 || col_raw >= c) continue;
-        if (training && blockIdx.x == 0) {
-            // running estimates as torch.nn.BatchNorm1d keeps them: unbiased variance, momentum update
-            const float unbiased = dm.g > 1 ? var * ((float)dm.g / (float)(dm.g - 1)) : var;
-            running_mean[col] = (1.f - momentum) * running_mean[col] + momentum * mean;
-            running_var[col] = (1.f - momentum) * running_var[col] + momentum * unbiased;
-            if (col == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
+        float mean = rm, var = rv;
+        if (training) mean = merge_stats8(partials, n_partials, c, col, lane8, first, &var);
+        if (lane8 == 0 && col_raw < c) {
+            if (training && blockIdx.x == 0) {
+                // running estimates as torch.nn.BatchNorm1d keeps them: unbiased variance, momentum update
+                const float unbiased = dm.g > 1 ? var * ((float)dm.g / (float)(dm.g - 1)) : var;
+                running_mean[col] = (1.f - momentum) * rm + momentum * mean;
+                running_var[col] = (1.f - momentum) * rv + momentum * unbiased;
+                if (col == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
+            }
+            const float invstd = 1.f / sqrtf(var + eps);
+            if (blockIdx.x == 0 && mean_out != nullptr) {
+                mean_out[col] = mean;
+                invstd_out[col] = invstd;
+            }
+            const float sc = ga * invstd;
+            s_scale[col] = sc;
+            s_shift[col] = be - mean * sc;
         }
-        const float invstd = 1.f / sqrtf(var + eps);
-        if (blockIdx.x == 0 && mean_out != nullptr) {
-            mean_out[col] = mean;
-            invstd_out[col] = invstd;
-        }
-        const float sc = bn_w[col] * invstd;
-        s_scale[col] = sc;
-        s_shift[col] = bn_b[col] - mean * sc;
-    }
+        c0 += kBlock / 8;
+    } while (c0 < c);
     __syncthreads();
 
     const bool drop = training && drop_p > 0.f;
@@ -273,14 +327,22 @@ head_bwd_tile_kernel(const float *__restrict__ k, HeadDims dm, const float *__re
     float *s_mu = s_be + c;                  // [c]
     float *s_is = s_mu + c;                  // [c]
     const int tid = threadIdx.x;
-    for (int i = tid; i < p * c; i += kBlock) s_w1[(i / c) * cs + i % c] = w1[i];
-    for (int i = tid; i < nc * p; i += kBlock) s_w2[(i / p) * ps + i % p] = w2[i];
-    for (int i = tid; i < nv; i += kBlock) s_g[i] = 0.f;
-    for (int i = tid; i < c; i += kBlock) {
-        s_ga[i] = bn_w[i];
-        s_be[i] = bn_b[i];
-        s_mu[i] = mean[i];
-        s_is[i] = invstd[i];
+    {   // all parameter loads in flight together, then the LDS stores
+        ParamChunk<4> r_w1;
+        ParamChunk<1> r_w2, r_ga, r_be, r_mu, r_is;
+        r_w1.load(w1, p * c, tid);
+        r_w2.load(w2, nc * p, tid);
+        r_ga.load(bn_w, c, tid);
+        r_be.load(bn_b, c, tid);
+        r_mu.load(mean, c, tid);
+        r_is.load(invstd, c, tid);
+        for (int i = tid; i < nv; i += kBlock) s_g[i] = 0.f;
+        r_w1.store_rows(w1, p * c, c, cs, s_w1, tid);
+        r_w2.store_rows(w2, nc * p, p, ps, s_w2, tid);
+        r_ga.store_rows(bn_w, c, c, c, s_ga, tid);
+        r_be.store_rows(bn_b, c, c, c, s_be, tid);
+        r_mu.store_rows(mean, c, c, c, s_mu, tid);
+        r_is.store_rows(invstd, c, c, c, s_is, tid);
     }
     __syncthreads();
 
@@ -355,6 +417,23 @@ head_bwd_tile_kernel(const float *__restrict__ k, HeadDims dm, const float *__re
     for (int e = tid; e < nv; e += kBlock) dst[e] = s_g[e];
 }
 
+// partials[b][e] added over b = lane8, lane8 + 8, ... in that order, eight loads in flight at a time
+__device__ inline float sum_partials8(const float *__restrict__ partials, int n_partials, int nv, int e, int lane8) {
+    float acc = 0.f;
+    for (int b0 = lane8; b0 < n_partials; b0 += 64) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int b = b0 + 8 * u;
+            v[u] = partials[(size_t)(b < n_partials ? b : n_partials - 1) * nv + e];
+            if (b >= n_partials) v[u] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    return acc;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // backward, second launch: parameter gradients (block partials added in block order) and dK
 // ---------------------------------------------------------------------------------------------------
@@ -376,8 +455,7 @@ head_bwd_finish_kernel(const float *__restrict__ k, HeadDims dm, const float *__
     for (int e0 = e_lo; e0 < e_hi; e0 += kBlock / 8) {      // uniform trip count: the shuffles need all lanes
         const int e = e0 + grp;
         const int ec = e < e_hi ? e : e_hi - 1;
-        float acc = 0.f;
-        for (int b = lane8; b < n_partials; b += 8) acc += partials[(size_t)b * nv + ec];
+        float acc = sum_partials8(partials, n_partials, nv, ec, lane8);
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
         acc += __shfl_xor(acc, 4, 64);
@@ -387,8 +465,7 @@ head_bwd_finish_kernel(const float *__restrict__ k, HeadDims dm, const float *__
     for (int c0 = 0; c0 < 2 * c; c0 += kBlock / 8) {
         const int q = c0 + grp;                              // q < c: dgamma column, else dbeta column
         const int qc = q < 2 * c ? q : 2 * c - 1;
-        float acc = 0.f;
-        for (int b = lane8; b < n_partials; b += 8) acc += partials[(size_t)b * nv + o_ga + qc];
+        float acc = sum_partials8(partials, n_partials, nv, o_ga + qc, lane8);
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
         acc += __shfl_xor(acc, 4, 64);

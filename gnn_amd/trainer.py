@@ -43,6 +43,8 @@ class Trainer:
         # F.cross_entropy(output, y) of main.py:85, one launch each way (gnn_amd.losses) or torch's own kernels
         self.loss_fn = cross_entropy if fused_loss else F.cross_entropy
         self.loss = None
+        # d(loss)/d(loss) = 1, kept resident: backward() would otherwise launch a fill for it every step
+        self._one = torch.ones((), dtype=torch.float32, device=self.feats.device)
         self.g_fb = None
         self.g_opt = None
 
@@ -50,7 +52,7 @@ class Trainer:
         self.bucket.release()            # optimizer.zero_grad(set_to_none=True)
         out = self.model(self.adj, self.feats, self.gi)
         self.loss = self.loss_fn(out, self.y)
-        self.loss.backward()
+        self.loss.backward(self._one)
         self.bucket.gather()             # per-parameter gradients -> the flat bucket, one launch
 
     def step_eager(self):
