@@ -4,7 +4,7 @@
 // kernel features; everything is tiny next to the random-walk layer, so the kernels are plain vector-ALU code
 // whose only aim is to be few launches, deterministic (fixed summation orders, no atomics) and exact fp32.
 //
-//   forward, training:  head_stats_kernel   per-block (count, mean, M2) of each column, merged with Chan's formula
+//   forward, training:  head_stats_kernel   per-block (count, mean, M2) of each column, merged by the pairwise-variance identity
 //                       head_apply_kernel   normalise, both linear layers, dropout, log-softmax; running stats
 //   backward:           head_bwd_tile_kernel  d(logits), d(pre-activations), dY; per-block partial parameter sums
 //                       head_bwd_finish_kernel  parameter gradients, batch-norm input gradient
@@ -14,8 +14,41 @@
 
 namespace {
 
+// Diagnostic build only (-DRWK_STAMP): cycle shares of the segments of head_apply_kernel (slots 0..7) and
+// head_bwd_tile_kernel (slots 8..15) for wavefront 0 of workgroup 1.
+#ifdef RWK_STAMP
+__device__ unsigned long long rwk_head_stamp_buf[16];
+#define HEAD_STAMP_DECL() unsigned long long st_last = __builtin_readcyclecounter()
+#define HEAD_STAMP_AT(k)                                                               \
+    do {                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        const unsigned long long now_ = __builtin_readcyclecounter();                  \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        if (blockIdx.x == 1 && threadIdx.x == 0) rwk_head_stamp_buf[k] = now_ - st_last; \
+        st_last = now_;                                                                \
+    } while (0)
+#else
+#define HEAD_STAMP_DECL()
+#define HEAD_STAMP_AT(k)
+#endif
+
 constexpr int kBlock = 256;
-constexpr int kRows = 16;
+constexpr int kRows = 8;
+
+// i / d and i % d for 0 <= i < 2^22, 1 <= d <= 2^14 in a handful of instructions (a 32-bit integer division by a
+// run-time value costs about forty): the float quotient is off by at most one, which the remainder corrects.
+struct FastDiv {
+    int d;
+    float inv;
+    __device__ explicit FastDiv(int d_) : d(d_), inv(1.0f / (float)d_) {}
+    __device__ inline int div(int i) const {
+        int q = (int)((float)i * inv);
+        const int r = i - q * d;
+        q += (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
+        return q;
+    }
+    __device__ inline int mod(int i) const { return i - div(i) * d; }
+};
 constexpr int kMaxBlocks = 256;
 constexpr int kMaxC = 256, kMaxNC = 32, kMaxPC = 4096;
 constexpr uint32_t kHeadCall = 0xFFFFFFFFu;       // Philox counter word no other mask of the model uses
@@ -86,21 +119,12 @@ head_stats_kernel(const float *__restrict__ k, long long g, int c, float *__rest
     }
 }
 
-// (n, mean, M2) <- merge of (n, mean, M2) and (nb, mb, qb)   (Chan et al.)
-__device__ inline void chan_merge(float &n, float &mean, float &m2, float nb, float mb, float qb) {
-    if (nb <= 0.f) return;
-    const float delta = mb - mean;
-    const float nn = n + nb;
-    mean += delta * (nb / nn);
-    m2 += qb + delta * delta * (n * nb / nn);
-    n = nn;
-}
-
-// Batch statistics of one column from the per-block partials, computed by 8 cooperating lanes (lane8 = 0..7 of
-// an aligned group): lane l merges blocks l, l+8, ... in order, then the eight results are merged pairwise, the
-// lower lane's value always on the left, so that every lane (and every workgroup) ends with the same bits.
-// The partials are fetched eight blocks at a time (24 loads in flight), then merged: a load per merge step would
-// cost a round trip to L2 each.
+// Batch statistics of one column from the per-block partials (count, mean, M2 about the block mean), computed by
+// 8 cooperating lanes (lane8 = 0..7 of an aligned group) with the pairwise-variance identity applied once over all
+// blocks:  mean = sum_b n_b mean_b / N,  M2 = sum_b (M2_b + n_b (mean_b - mean)^2).  Lane l adds blocks l, l+8, ...
+// in order, the eight sums are added in a butterfly whose operand pairs are the same on every lane, so every lane
+// (and every workgroup) ends with the same bits.  Two divisions per column; the partials are fetched eight blocks
+// at a time (24 loads in flight) - a load per step would cost a round trip to L2 each.
 struct StatsChunk {
     float n[8], mean[8], m2[8];
     __device__ inline void load(const float *__restrict__ partials, int n_blocks, int c, int col, int b0) {
@@ -111,31 +135,58 @@ struct StatsChunk {
             n[u] = p[0];
             mean[u] = p[1 + col];
             m2[u] = p[1 + c + col];
-            if (b >= n_blocks) n[u] = 0.f;                // merged as an empty block
+            if (b >= n_blocks) {                          // counts as an empty block
+                n[u] = 0.f;
+                m2[u] = 0.f;
+            }
         }
     }
 };
 
+__device__ inline float sum8(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    return v;
+}
+
 __device__ inline float merge_stats8(const float *__restrict__ partials, int n_blocks, int c, int col, int lane8,
-                                     StatsChunk &first, float *var) {
-    float n = 0.f, mean = 0.f, m2 = 0.f;
+                                     const StatsChunk &first, float *var) {
+    float sn = 0.f, sm = 0.f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) chan_merge(n, mean, m2, first.n[u], first.mean[u], first.m2[u]);
+    for (int u = 0; u < 8; ++u) {
+        sn += first.n[u];
+        sm = fmaf(first.n[u], first.mean[u], sm);
+    }
     for (int b0 = lane8 + 64; b0 < n_blocks; b0 += 64) {
         StatsChunk next;
         next.load(partials, n_blocks, c, col, b0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) chan_merge(n, mean, m2, next.n[u], next.mean[u], next.m2[u]);
+        for (int u = 0; u < 8; ++u) {
+            sn += next.n[u];
+            sm = fmaf(next.n[u], next.mean[u], sm);
+        }
     }
+    sn = sum8(sn);
+    sm = sum8(sm);
+    const float mean = sn > 0.f ? sm / sn : 0.f;
+    float q = 0.f;
 #pragma unroll
-    for (int off = 1; off < 8; off <<= 1) {
-        const float on = __shfl_xor(n, off, 64), om = __shfl_xor(mean, off, 64), oq = __shfl_xor(m2, off, 64);
-        const bool upper = (lane8 & off) != 0;
-        float ln = upper ? on : n, lm = upper ? om : mean, lq = upper ? oq : m2;
-        chan_merge(ln, lm, lq, upper ? n : on, upper ? mean : om, upper ? m2 : oq);
-        n = ln; mean = lm; m2 = lq;
+    for (int u = 0; u < 8; ++u) {
+        const float dv = first.mean[u] - mean;
+        q += fmaf(first.n[u] * dv, dv, first.m2[u]);
     }
-    *var = n > 0.f ? m2 / n : 0.f;
+    for (int b0 = lane8 + 64; b0 < n_blocks; b0 += 64) {
+        StatsChunk next;
+        next.load(partials, n_blocks, c, col, b0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float dv = next.mean[u] - mean;
+            q += fmaf(next.n[u] * dv, dv, next.m2[u]);
+        }
+    }
+    q = sum8(q);
+    *var = sn > 0.f ? q / sn : 0.f;
     return mean;
 }
 
@@ -152,13 +203,26 @@ struct ParamChunk {
         }
     }
     // dst[(i / w) * ws + i % w] = src[i]; elements beyond the chunk are copied by a plain loop
-    __device__ inline void store_rows(const float *__restrict__ src, int n, int w, int ws, float *dst, int tid) const {
+    __device__ inline void store_rows(const float *__restrict__ src, int n, const FastDiv &w, int ws, float *dst,
+                                      int tid) const {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = tid + u * kBlock;
-            if (i < n) dst[(i / w) * ws + i % w] = v[u];
+            const int r = w.div(i);
+            if (i < n) dst[r * ws + (i - r * w.d)] = v[u];
         }
-        for (int i = tid + U * kBlock; i < n; i += kBlock) dst[(i / w) * ws + i % w] = src[i];
+        for (int i = tid + U * kBlock; i < n; i += kBlock) {
+            const int r = w.div(i);
+            dst[r * ws + (i - r * w.d)] = src[i];
+        }
+    }
+    __device__ inline void store_flat(const float *__restrict__ src, int n, float *dst, int tid) const {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = tid + u * kBlock;
+            if (i < n) dst[i] = v[u];
+        }
+        for (int i = tid + U * kBlock; i < n; i += kBlock) dst[i] = src[i];
     }
 };
 
@@ -191,14 +255,22 @@ head_apply_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
     float *s_h = s_y + kRows * cs;           // [kRows][ps]
     float *s_o = s_h + kRows * ps;           // [kRows][nc]
     const int tid = threadIdx.x;
+    const FastDiv by_c(c), by_p(p), by_nc(nc);
+    HEAD_STAMP_DECL();
 
     // all parameter loads and the first chunk of batch-statistics partials in flight together
     ParamChunk<4> r_w1;
     ParamChunk<1> r_w2, r_b1, r_b2;
+    ParamChunk<2> r_k;                                        // first elements of this block's first tile
     r_w1.load(w1, p * c, tid);
     r_w2.load(w2, nc * p, tid);
     r_b1.load(b1, p, tid);
     r_b2.load(b2, nc, tid);
+    {
+        const long long r0 = (long long)blockIdx.x * kRows;   // blockIdx.x < number of tiles
+        const int nr = (int)(dm.g - r0 < kRows ? dm.g - r0 : kRows);
+        r_k.load(k + r0 * c, nr * c, tid);
+    }
     const int lane8 = tid & 7;
     int c0 = 0;
     do {                                                      // uniform trip count: the shuffles need all lanes
@@ -208,10 +280,10 @@ head_apply_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
         if (training) first.load(partials, n_partials, c, col, lane8);
         const float rm = running_mean[col], rv = running_var[col], ga = bn_w[col], be = bn_b[col];
         if (c0 == 0) {
-            r_w1.store_rows(w1, p * c, c, cs, s_w1, tid);
-            r_w2.store_rows(w2, nc * p, p, ps, s_w2, tid);
-            r_b1.store_rows(b1, p, p, p, s_b1, tid);
-            r_b2.store_rows(b2, nc, nc, nc, s_b2, tid);
+            r_w1.store_rows(w1, p * c, by_c, cs, s_w1, tid);
+            r_w2.store_rows(w2, nc * p, by_p, ps, s_w2, tid);
+            r_b1.store_flat(b1, p, s_b1, tid);
+            r_b2.store_flat(b2, nc, s_b2, tid);
         }
         float mean = rm, var = rv;
         if (training) mean = merge_stats8(partials, n_partials, c, col, lane8, first, &var);
@@ -235,6 +307,7 @@ head_apply_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
         c0 += kBlock / 8;
     } while (c0 < c);
     __syncthreads();
+    HEAD_STAMP_AT(0);
 
     const bool drop = training && drop_p > 0.f;
     uint32_t seed_lo = 0, key_hi = 0, off_lo = 0, keep_thr = 0xFFFFFFFFu;
@@ -254,13 +327,21 @@ head_apply_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
     for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const long long r0 = t * kRows;
         const int nr = (int)(dm.g - r0 < kRows ? dm.g - r0 : kRows);
-        for (int i = tid; i < nr * c; i += kBlock) {
-            const int r = i / c, col = i % c;
+        const bool first_tile = t == blockIdx.x;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * kBlock;
+            const int r = by_c.div(i), col = i - r * c;
+            if (first_tile && i < nr * c) s_y[r * cs + col] = fmaf(r_k.v[u], s_scale[col], s_shift[col]);
+        }
+        for (int i = tid + (first_tile ? 2 * kBlock : 0); i < nr * c; i += kBlock) {
+            const int r = by_c.div(i), col = i - r * c;
             s_y[r * cs + col] = fmaf(k[(r0 + r) * c + col], s_scale[col], s_shift[col]);
         }
         __syncthreads();
+        HEAD_STAMP_AT(1);
         for (int i = tid; i < nr * p; i += kBlock) {
-            const int r = i / p, j = i % p;
+            const int r = by_p.div(i), j = i - r * p;
             float acc = s_b1[j];
             const float *yr = s_y + r * cs, *wr = s_w1 + j * cs;
 #pragma unroll 8
@@ -276,8 +357,9 @@ head_apply_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
             if (h1d_out != nullptr) h1d_out[(r0 + r) * p + j] = acc;
         }
         __syncthreads();
+        HEAD_STAMP_AT(2);
         for (int i = tid; i < nr * nc; i += kBlock) {
-            const int r = i / nc, q = i % nc;
+            const int r = by_nc.div(i), q = i - r * nc;
             float acc = s_b2[q];
             const float *hr = s_h + r * ps, *wr = s_w2 + q * ps;
 #pragma unroll 8
@@ -285,6 +367,7 @@ head_apply_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
             s_o[r * nc + q] = acc;
         }
         __syncthreads();
+        HEAD_STAMP_AT(3);
         if (tid < nr) {
             const float *o = s_o + tid * nc;
             float mx = o[0];
@@ -295,6 +378,7 @@ head_apply_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
             for (int q = 0; q < nc; ++q) out[(r0 + tid) * nc + q] = o[q] - lse;
         }
         __syncthreads();
+        HEAD_STAMP_AT(4);
     }
 }
 
@@ -324,55 +408,77 @@ head_bwd_tile_kernel(const float *__restrict__ k, HeadDims dm, const float *__re
     float *s_g = s_dl + kRows * nc;          // [nv]
     float *s_ga = s_g + nv;                  // [c] batch-norm weight
     float *s_be = s_ga + c;                  // [c] batch-norm bias
-    float *s_mu = s_be + c;                  // [c]
-    float *s_is = s_mu + c;                  // [c]
     const int tid = threadIdx.x;
-    {   // all parameter loads in flight together, then the LDS stores
-        ParamChunk<4> r_w1;
-        ParamChunk<1> r_w2, r_ga, r_be, r_mu, r_is;
-        r_w1.load(w1, p * c, tid);
-        r_w2.load(w2, nc * p, tid);
-        r_ga.load(bn_w, c, tid);
-        r_be.load(bn_b, c, tid);
-        r_mu.load(mean, c, tid);
-        r_is.load(invstd, c, tid);
-        for (int i = tid; i < nv; i += kBlock) s_g[i] = 0.f;
-        r_w1.store_rows(w1, p * c, c, cs, s_w1, tid);
-        r_w2.store_rows(w2, nc * p, p, ps, s_w2, tid);
-        r_ga.store_rows(bn_w, c, c, c, s_ga, tid);
-        r_be.store_rows(bn_b, c, c, c, s_be, tid);
-        r_mu.store_rows(mean, c, c, c, s_mu, tid);
-        r_is.store_rows(invstd, c, c, c, s_is, tid);
-    }
-    __syncthreads();
+    const FastDiv by_c(c), by_p(p);
+    HEAD_STAMP_DECL();
+    // all parameter loads in flight together; their LDS stores follow the first tile's own loads (below), so that
+    // one round trip to memory covers both
+    ParamChunk<4> r_w1;
+    ParamChunk<1> r_w2, r_ga, r_be;
+    r_w1.load(w1, p * c, tid);
+    r_w2.load(w2, nc * p, tid);
+    r_ga.load(bn_w, c, tid);
+    r_be.load(bn_b, c, tid);
+    for (int i = tid; i < nv; i += kBlock) s_g[i] = 0.f;
 
     const int o_b2 = nc * p, o_w1 = o_b2 + nc, o_b1 = o_w1 + p * c, o_ga = o_b1 + p, o_be = o_ga + c;
     const long long n_tiles = (dm.g + kRows - 1) / kRows;
     for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const long long r0 = t * kRows;
         const int nr = (int)(dm.g - r0 < kRows ? dm.g - r0 : kRows);
-        for (int i = tid; i < nr * c; i += kBlock) {
-            const int r = i / c, col = i % c;
-            s_xh[r * cs + col] = (k[(r0 + r) * c + col] - s_mu[col]) * s_is[col];
+        // the tile's loads first (two elements per thread of each array; the rest, for wide layers, in plain
+        // loops), then the stores
+        ParamChunk<2> t_k, t_h;
+        float t_mu[2], t_is[2];
+        t_k.load(k + r0 * c, nr * c, tid);
+        t_h.load(h1d + r0 * p, nr * p, tid);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * kBlock;
+            const int col = by_c.mod(i < nr * c ? i : nr * c - 1);
+            t_mu[u] = mean[col];
+            t_is[u] = invstd[col];
         }
-        for (int i = tid; i < nr * p; i += kBlock) s_h[(i / p) * ps + i % p] = h1d[r0 * p + i];
         if (tid < nr) {                                  // log-softmax backward, one row per thread
             const float *go = d_out + (r0 + tid) * nc, *lo = out + (r0 + tid) * nc;
             float s = 0.f;
             for (int q = 0; q < nc; ++q) s += go[q];
             for (int q = 0; q < nc; ++q) s_dl[tid * nc + q] = go[q] - expf(lo[q]) * s;
         }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * kBlock;
+            const int rc = by_c.div(i), rp = by_p.div(i);
+            if (i < nr * c) s_xh[rc * cs + (i - rc * c)] = (t_k.v[u] - t_mu[u]) * t_is[u];
+            if (i < nr * p) s_h[rp * ps + (i - rp * p)] = t_h.v[u];
+        }
+        for (int i = tid + 2 * kBlock; i < nr * c; i += kBlock) {
+            const int r = by_c.div(i), col = i - r * c;
+            s_xh[r * cs + col] = (k[(r0 + r) * c + col] - mean[col]) * invstd[col];
+        }
+        for (int i = tid + 2 * kBlock; i < nr * p; i += kBlock) {
+            const int r = by_p.div(i);
+            s_h[r * ps + (i - r * p)] = h1d[r0 * p + i];
+        }
+        if (t == blockIdx.x) {
+            r_w1.store_rows(w1, p * c, by_c, cs, s_w1, tid);
+            r_w2.store_rows(w2, nc * p, by_p, ps, s_w2, tid);
+            r_ga.store_flat(bn_w, c, s_ga, tid);
+            r_be.store_flat(bn_b, c, s_be, tid);
+        }
         __syncthreads();
+        HEAD_STAMP_AT(8);
         for (int i = tid; i < nr * p; i += kBlock) {
-            const int r = i / p, j = i % p;
+            const int r = by_p.div(i), j = i - r * p;
             float acc = 0.f;
 #pragma unroll 8
             for (int q = 0; q < nc; ++q) acc = fmaf(s_dl[r * nc + q], s_w2[q * ps + j], acc);
             s_dp[r * ps + j] = s_h[r * ps + j] > 0.f ? acc * keep_scale : 0.f;
         }
         __syncthreads();
+        HEAD_STAMP_AT(9);
         for (int i = tid; i < nr * c; i += kBlock) {
-            const int r = i / c, col = i % c;
+            const int r = by_c.div(i), col = i - r * c;
             float acc = 0.f;
 #pragma unroll 8
             for (int j = 0; j < p; ++j) acc = fmaf(s_dp[r * ps + j], s_w1[j * cs + col], acc);
@@ -380,11 +486,12 @@ head_bwd_tile_kernel(const float *__restrict__ k, HeadDims dm, const float *__re
             dy[(r0 + r) * c + col] = acc;
         }
         __syncthreads();
+        HEAD_STAMP_AT(10);
         // every thread owns the gradient elements e = tid, tid + 256, ...: rows are added in row order
         for (int e = tid; e < nv; e += kBlock) {
             float acc = 0.f;
             if (e < o_b2) {
-                const int q = e / p, j = e % p;
+                const int q = by_p.div(e), j = e - q * p;
 #pragma unroll 8
                 for (int r = 0; r < nr; ++r) acc = fmaf(s_dl[r * nc + q], s_h[r * ps + j], acc);
             } else if (e < o_w1) {
@@ -392,7 +499,7 @@ head_bwd_tile_kernel(const float *__restrict__ k, HeadDims dm, const float *__re
 #pragma unroll 8
                 for (int r = 0; r < nr; ++r) acc += s_dl[r * nc + q];
             } else if (e < o_b1) {
-                const int j = (e - o_w1) / c, col = (e - o_w1) % c;
+                const int j = by_c.div(e - o_w1), col = (e - o_w1) - j * c;
                 const float ga = s_ga[col], be = s_be[col];
 #pragma unroll 8
                 for (int r = 0; r < nr; ++r) acc = fmaf(s_dp[r * ps + j], fmaf(s_xh[r * cs + col], ga, be), acc);
@@ -412,9 +519,11 @@ head_bwd_tile_kernel(const float *__restrict__ k, HeadDims dm, const float *__re
             s_g[e] += acc;
         }
         __syncthreads();
+        HEAD_STAMP_AT(11);
     }
     float *dst = partials + (size_t)blockIdx.x * nv;
     for (int e = tid; e < nv; e += kBlock) dst[e] = s_g[e];
+    HEAD_STAMP_AT(12);
 }
 
 // partials[b][e] added over b = lane8, lane8 + 8, ... in that order, eight loads in flight at a time
@@ -475,12 +584,13 @@ head_bwd_finish_kernel(const float *__restrict__ k, HeadDims dm, const float *__
     }
     __syncthreads();
     const float inv_g = 1.f / (float)dm.g;
+    const FastDiv by_c(c);
     const long long n_tiles = (dm.g + kRows - 1) / kRows;
     for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const long long r0 = t * kRows;
         const int nr = (int)(dm.g - r0 < kRows ? dm.g - r0 : kRows);
         for (int i = tid; i < nr * c; i += kBlock) {
-            const int col = i % c;
+            const int col = by_c.mod(i);
             const long long at = r0 * c + i;
             const float sc = bn_w[col] * invstd[col];
             float v = dy[at];
@@ -546,7 +656,7 @@ size_t fwd_lds(int c, int p, int nc) {
 }
 size_t bwd_lds(int c, int p, int nc) {
     return sizeof(float) * ((size_t)p * (c + 1) + (size_t)nc * (p + 1) + 2 * (size_t)kRows * (c + 1) +
-                            2 * (size_t)kRows * (p + 1) + (size_t)kRows * nc + head_nv(c, p, nc) + 4 * (size_t)c);
+                            2 * (size_t)kRows * (p + 1) + (size_t)kRows * nc + head_nv(c, p, nc) + 2 * (size_t)c);
 }
 
 bool dims_ok(int64_t g, int64_t c, int64_t p, int64_t nc) {
@@ -566,6 +676,12 @@ int allow_lds(K kern, size_t lds) {
 }  // namespace
 
 extern "C" {
+
+#ifdef RWK_STAMP
+int rwk_debug_read_head_stamps(unsigned long long *host16) {
+    return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(rwk_head_stamp_buf), sizeof(unsigned long long) * 16);
+}
+#endif
 
 int rwk_head_supported(int64_t g, int64_t c, int64_t p, int64_t nc) {
     return dims_ok(g, c, p, nc) && bwd_lds((int)c, (int)p, (int)nc) <= 150 * 1024 ? 1 : 0;

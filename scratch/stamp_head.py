@@ -1,0 +1,26 @@
+"""Diagnostic: cycle shares of the head kernels (library built with -DRWK_STAMP as scratch/librwk_stamp.so)."""
+import sys, ctypes, numpy as np, torch
+sys.path.insert(0, '.')
+from gnn_amd import _lib
+_lib.LIB_PATH = 'scratch/librwk_stamp.so'
+from gnn_amd import RW_NN
+from gnn_amd.synth import CONFIGS, config_batch
+from gnn_amd.trainer import Trainer
+dev = torch.device('cuda:0')
+hp = dict(CONFIGS['proteins1024']['hp'])
+b = config_batch('proteins1024', 1)
+bt = b.to_torch(dev)
+m = RW_NN(hp["input_dim"], hp["max_step"], hp["hidden_graphs"], hp["size_hidden_graphs"], hp["hidden_dim"],
+          hp["penultimate_dim"], bool(hp["normalize"]), hp["n_classes"], hp["dropout"], dev).to(dev)
+m.train()
+tr = Trainer(m, bt, 1)
+for _ in range(5):
+    tr.step_eager()
+torch.cuda.synchronize()
+lib = _lib.load()
+buf = (ctypes.c_uint64 * 16)()
+lib.rwk_debug_read_head_stamps.restype = ctypes.c_int
+print('rc', lib.rwk_debug_read_head_stamps(buf))
+a = list(buf)
+print('apply   : stats+params %d | s_y %d | fc1+dropout %d | fc2 %d | log-softmax %d' % tuple(a[0:5]))
+print('bwd_tile: loads+stores %d | d pre-act %d | dY %d | param grads %d | write partials %d' % tuple(a[8:13]))
