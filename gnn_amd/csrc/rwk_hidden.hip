@@ -93,7 +93,17 @@ hidden_backward_kernel(const float *__restrict__ adj_hidden, const float *__rest
         const int step = v / sd, e = v % sd;
         const float *src = dz_partials + step * step_stride + (size_t)h * sd + e;
         float acc = 0.f;
-        for (int p = q; p < n_partials; p += n_slices) acc += src[(size_t)p * part_stride];
+        for (int p0 = q; p0 < n_partials; p0 += 8 * n_slices) {     // eight loads in flight, added in order
+            float part[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p = p0 + u * n_slices;
+                part[u] = src[(size_t)(p < n_partials ? p : n_partials - 1) * part_stride];
+                if (p >= n_partials) part[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += part[u];
+        }
         slice[w] = acc;
     }
     for (int i = tid; i < s * s; i += kBlock) {

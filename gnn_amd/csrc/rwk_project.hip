@@ -11,19 +11,41 @@ namespace {
 
 constexpr int kBlock = 256;
 
-// one thread per (node, output channel)
+// one thread per (node, output channel); 32-bit index arithmetic (n * d < 2^31 is checked by the launcher)
 __global__ void __launch_bounds__(kBlock)
 project_forward_kernel(const float *__restrict__ feat, const float *__restrict__ w, const float *__restrict__ b,
-                       long long n, int f, int d, float *__restrict__ x0) {
-    const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (t >= n * d) return;
-    const long long node = t / d;
-    const int c = (int)(t % d);
+                       int n, int f, int d, float *__restrict__ x0) {
+    const unsigned t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (unsigned)n * (unsigned)d) return;
+    const unsigned node = t / (unsigned)d;
+    const int c = (int)(t - node * (unsigned)d);
     float acc = b[c];
-    const float *fr = feat + node * f;
+    const float *fr = feat + (size_t)node * f;
     const float *wr = w + (size_t)c * f;
     for (int k = 0; k < f; ++k) acc = fmaf(fr[k], wr[k], acc);
     x0[t] = 1.0f / (1.0f + expf(-acc));
+}
+
+// hidden_dim 4 (the reference's default): one thread per node, one 16-byte store per row
+template <int FP>
+__global__ void __launch_bounds__(kBlock)
+project_forward4_kernel(const float *__restrict__ feat, const float *__restrict__ w, const float *__restrict__ b,
+                        int n, int f, float *__restrict__ x0) {
+    const int node = blockIdx.x * kBlock + threadIdx.x;
+    if (node >= n) return;
+    float fr[FP];
+#pragma unroll
+    for (int k = 0; k < FP; ++k) fr[k] = feat[(size_t)node * f + (k < f ? k : f - 1)];
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float acc = b[c];
+#pragma unroll
+        for (int k = 0; k < FP; ++k)
+            if (k < f) acc = fmaf(fr[k], w[c * f + k], acc);
+        o[c] = 1.0f / (1.0f + expf(-acc));
+    }
+    reinterpret_cast<float4 *>(x0)[node] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // Thread (slot, c): c = output channel, slot strides over nodes.  FP = padded input width.
@@ -46,31 +68,37 @@ project_backward_kernel(const float *__restrict__ dx0, const float *__restrict__
     float wr[FP];
 #pragma unroll
     for (int k = 0; k < FP; ++k) wr[k] = (own && k < f) ? w[(size_t)c * f + k] : 0.f;
-    // uniform trip count so that the optional group sum sees every lane
+    // uniform trip count so that the optional group sum sees every lane; the loads of four rounds are issued
+    // together (unconditional, at clamped indices), then the rounds are added in order
     const long long per_round = (long long)gridDim.x * slots;
     const long long rounds = (n + per_round - 1) / per_round;
-    for (long long r = 0; r < rounds; ++r) {
-        const long long node = r * per_round + (long long)blockIdx.x * slots + slot;
-        const bool valid = node < n && own;
-        float dpre = 0.f;
-        float fr[FP];
+    const int cc = own ? c : d - 1;
+    for (long long r0 = 0; r0 < rounds; r0 += 4) {
+        float xv[4], dv[4], fr[4][FP];
 #pragma unroll
-        for (int k = 0; k < FP; ++k) fr[k] = 0.f;
-        if (valid) {
-            const float xv = x0[node * d + c];
-            dpre = dx0[node * d + c] * xv * (1.0f - xv);
+        for (int u = 0; u < 4; ++u) {
+            const long long node = (r0 + u) * per_round + (long long)blockIdx.x * slots + slot;
+            const long long nc = node < n ? node : n - 1;
+            xv[u] = x0[nc * d + cc];
+            dv[u] = dx0[nc * d + cc];
 #pragma unroll
-            for (int k = 0; k < FP; ++k)
-                if (k < f) fr[k] = feat[node * f + k];
+            for (int k = 0; k < FP; ++k) fr[u][k] = feat[nc * f + (k < f ? k : f - 1)];
         }
-        acc_b += dpre;
 #pragma unroll
-        for (int k = 0; k < FP; ++k) acc_w[k] = fmaf(dpre, fr[k], acc_w[k]);
-        if (d_feat != nullptr) {
+        for (int u = 0; u < 4; ++u) {
+            if (r0 + u >= rounds) break;                  // uniform
+            const long long node = (r0 + u) * per_round + (long long)blockIdx.x * slots + slot;
+            const bool valid = node < n && own;
+            const float dpre = valid ? dv[u] * xv[u] * (1.0f - xv[u]) : 0.f;
+            acc_b += dpre;
 #pragma unroll
-            for (int k = 0; k < FP; ++k) {
-                const float v = rwk_group_sum(dpre * wr[k], dpad);
-                if (node < n && c == 0 && k < f) d_feat[node * f + k] = v;
+            for (int k = 0; k < FP; ++k) acc_w[k] = fmaf(dpre, (valid && k < f) ? fr[u][k] : 0.f, acc_w[k]);
+            if (d_feat != nullptr) {
+#pragma unroll
+                for (int k = 0; k < FP; ++k) {
+                    const float v = rwk_group_sum(dpre * wr[k], dpad);
+                    if (node < n && c == 0 && k < f) d_feat[node * f + k] = v;
+                }
             }
         }
     }
@@ -195,9 +223,21 @@ int rwk_project_forward(const float *features, const float *weight, const float 
     RWK_REQUIRE_PTR(weight);
     RWK_REQUIRE_PTR(bias);
     RWK_REQUIRE_PTR(x0);
-    if (n <= 0 || f <= 0 || d <= 0 || n * d >= 0x7FFFFFFFll * kBlock) return RWK_E_SIZE;
-    hipLaunchKernelGGL(project_forward_kernel, dim3((unsigned)rwk_ceil_div(n * d, kBlock)), dim3(kBlock), 0,
-                       (hipStream_t)stream, features, weight, bias, (long long)n, (int)f, (int)d, x0);
+    if (n <= 0 || f <= 0 || d <= 0 || n * d >= 0x7FFFFFFFll) return RWK_E_SIZE;
+    hipStream_t s = (hipStream_t)stream;
+    if (d == 4 && f <= 8 && ((uintptr_t)x0 & 15u) == 0) {
+        const dim3 grid((unsigned)rwk_ceil_div(n, kBlock));
+#define RWK_PF(FP) \
+    hipLaunchKernelGGL((project_forward4_kernel<FP>), grid, dim3(kBlock), 0, s, features, weight, bias, (int)n, (int)f, x0)
+        if (f == 1) RWK_PF(1);
+        else if (f == 2) RWK_PF(2);
+        else if (f <= 4) RWK_PF(4);
+        else RWK_PF(8);
+#undef RWK_PF
+    } else {
+        hipLaunchKernelGGL(project_forward_kernel, dim3((unsigned)rwk_ceil_div(n * d, kBlock)), dim3(kBlock), 0, s,
+                           features, weight, bias, (int)n, (int)f, (int)d, x0);
+    }
     RWK_LAUNCH_CHECK();
     return RWK_OK;
 }
