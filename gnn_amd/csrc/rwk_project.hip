@@ -167,6 +167,39 @@ reduce_rows_final_kernel(const float *__restrict__ in, int p, long long v, float
 
 constexpr int kMaxFinalRows = 32;
 
+// Few columns (v <= 64) and up to a few thousand rows in ONE launch: a workgroup of 1024 threads gives every
+// column 1024/vp lanes (vp = v rounded up to a power of two); lane l adds rows l, l + lanes, ... in order (four
+// loads in flight), then the lanes of a column are added in a fixed halving tree through LDS.
+constexpr int kSmallBlock = 1024;
+constexpr int kSmallMaxV = 64;
+
+__global__ void __launch_bounds__(kSmallBlock)
+reduce_rows_small_kernel(const float *__restrict__ in, int p, int v, int vp, float *__restrict__ out) {
+    __shared__ float red[kSmallBlock];
+    const int tid = threadIdx.x;
+    const int col = tid % vp, lane = tid / vp, lanes = kSmallBlock / vp;
+    const int cc = col < v ? col : v - 1;
+    float acc = 0.f;
+    for (int r0 = lane; r0 < p; r0 += 4 * lanes) {
+        float a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u * lanes;
+            a[u] = in[(size_t)(r < p ? r : p - 1) * v + cc];
+            if (r >= p) a[u] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += a[u];
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int off = lanes / 2; off >= 1; off >>= 1) {
+        if (lane < off) red[tid] += red[tid + off * vp];
+        __syncthreads();
+    }
+    if (lane == 0 && col < v) out[col] = red[col];
+}
+
 inline int pow2_ceil(int x) {
     int p = 1;
     while (p < x) p <<= 1;
@@ -202,6 +235,12 @@ int rwk_reduce_rows(const float *in, int64_t p, int64_t v, float *out, float *wo
     RWK_REQUIRE_PTR(in);
     RWK_REQUIRE_PTR(out);
     if (p <= 0 || v <= 0 || v >= 0x7FFFFFFFll * 64) return RWK_E_SIZE;
+    if (v <= kSmallMaxV && p > kMaxFinalRows && p <= 1 << 20) {
+        hipLaunchKernelGGL(reduce_rows_small_kernel, dim3(1), dim3(kSmallBlock), 0, (hipStream_t)stream, in, (int)p,
+                           (int)v, pow2_ceil((int)v), out);
+        RWK_LAUNCH_CHECK();
+        return RWK_OK;
+    }
     const float *src = in;
     int rows = (int)p;
     if (p > kMaxFinalRows) {

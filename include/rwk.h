@@ -268,8 +268,9 @@ int rwk_project_backward(const float *dx0, const float *x0, const float *feature
                          float *d_features, rwk_stream_t stream);
 
 /* out[v] = sum_p in[p, v], rows added in a fixed order (p > 32: 32 row blocks of ceil(p/32) rows,
- * each summed by 4 interleaved slices, then the 32 block sums in index order), so the result is
- * bitwise reproducible.  workspace: rwk_reduce_rows_workspace(p, v) floats (0 when p <= 32). */
+ * each summed by 4 interleaved slices, then the 32 block sums in index order; v <= 64 columns: one
+ * launch, interleaved lanes per column and a halving tree), so the result is bitwise
+ * reproducible.  workspace: rwk_reduce_rows_workspace(p, v) floats (0 when p <= 32). */
 int64_t rwk_reduce_rows_workspace(int64_t p, int64_t v);
 int rwk_reduce_rows(const float *in, int64_t p, int64_t v, float *out, float *workspace,
                     rwk_stream_t stream);
