@@ -61,6 +61,8 @@ SIGNATURES = {
     "rwk_gather_chunks": (c_int, [_P, _P, _I64, _P, _P]),
     "rwk_adam_n_counters": (_I64, [_I64]),
     "rwk_adam_step": (c_int, [_P, _P, _P, _P, _I64, _P, c_float, c_float, c_float, c_float, _P, _P]),
+    "rwk_adam_step_chunks": (c_int, [_P, _P, _P, _I64, _P, _P, _P, _I64, _P, c_float, c_float, c_float, c_float, _P,
+                                     _P]),
     "rwk_dropout_mask": (c_int, [_P, _I64, _I64, _I64, _I64, c_float, _P, _P]),
 }
 

@@ -35,6 +35,54 @@ adam_step_kernel(float *__restrict__ param, const float *__restrict__ grad, floa
     param[i] = p - (lr / corr[0]) * (m / denom);
 }
 
+// The same update with the gradient taken straight from up to 16 per-parameter gradient tensors (chunk k covers
+// the flat indices [off[k], off[k+1])), so that a single-process step needs no separate gather launch; the flat
+// gradient is still written to grad_out when that is not null.
+constexpr int kAdamChunks = 16;
+struct AdamChunks {
+    const float *src[kAdamChunks];
+    long long off[kAdamChunks];          // unused entries: LLONG_MAX
+};
+
+__global__ void __launch_bounds__(kBlock)
+adam_step_chunks_kernel(float *__restrict__ param, AdamChunks a, float *__restrict__ grad_out,
+                        float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq, long long n,
+                        const float *__restrict__ lr_ptr, float beta1, float beta2, float eps, float weight_decay,
+                        long long *__restrict__ step_counters) {
+    __shared__ float corr[2];
+    if (threadIdx.x == 0) {
+        const long long t = step_counters[blockIdx.x] + 1;
+        step_counters[blockIdx.x] = t;
+        corr[0] = (float)(1.0 - pow((double)beta1, (double)t));
+        corr[1] = (float)sqrt(1.0 - pow((double)beta2, (double)t));
+    }
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long ic = i < n ? i : n - 1;
+    // compare-select chain instead of indexing the argument table (a dynamic index would move it to scratch)
+    const float *src = a.src[0];
+    long long base = a.off[0];
+#pragma unroll
+    for (int k = 1; k < kAdamChunks; ++k) {
+        const bool ge = ic >= a.off[k];
+        src = ge ? a.src[k] : src;
+        base = ge ? a.off[k] : base;
+    }
+    float g = src ? src[ic - base] : 0.f;
+    float p = param[ic];
+    const float m0 = exp_avg[ic], v0 = exp_avg_sq[ic];
+    const float lr = lr_ptr[0];
+    __syncthreads();
+    if (i >= n) return;
+    if (grad_out != nullptr) grad_out[i] = g;
+    if (weight_decay != 0.f) g = fmaf(weight_decay, p, g);
+    const float m = fmaf(beta1, m0, (1.f - beta1) * g);
+    const float v = fmaf(beta2, v0, (1.f - beta2) * g * g);
+    exp_avg[i] = m;
+    exp_avg_sq[i] = v;
+    const float denom = sqrtf(v) / corr[1] + eps;
+    param[i] = p - (lr / corr[0]) * (m / denom);
+}
+
 constexpr int kGatherMax = 16;
 struct GatherArgs {
     const float *src[kGatherMax];
@@ -86,6 +134,35 @@ int rwk_gather_chunks(const float *const *srcs, const int64_t *sizes, int64_t n_
         hipLaunchKernelGGL(gather_chunks_kernel, dim3((unsigned)bx, (unsigned)m), dim3(kBlock), 0, stream, a, dst);
         RWK_LAUNCH_CHECK();
     }
+    return RWK_OK;
+}
+
+int rwk_adam_step_chunks(float *param, const float *const *srcs, const int64_t *sizes, int64_t n_chunks,
+                         float *grad_out, float *exp_avg, float *exp_avg_sq, int64_t n, const float *lr, float beta1,
+                         float beta2, float eps, float weight_decay, int64_t *step_counters, rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(param);
+    RWK_REQUIRE_PTR(srcs);
+    RWK_REQUIRE_PTR(sizes);
+    RWK_REQUIRE_PTR(exp_avg);
+    RWK_REQUIRE_PTR(exp_avg_sq);
+    RWK_REQUIRE_PTR(lr);
+    RWK_REQUIRE_PTR(step_counters);
+    if (n <= 0 || n >= 0x7FFFFFFFll * kBlock || n_chunks < 1) return RWK_E_SIZE;
+    if (n_chunks > kAdamChunks) return RWK_E_UNSUPPORTED;
+    AdamChunks a;
+    long long off = 0;
+    for (int k = 0; k < kAdamChunks; ++k) {
+        const bool used = k < n_chunks;
+        if (used && sizes[k] < 0) return RWK_E_SIZE;
+        a.src[k] = used ? srcs[k] : nullptr;
+        a.off[k] = used ? off : 0x7FFFFFFFFFFFFFFFll;
+        if (used) off += sizes[k];
+    }
+    if (off != n) return RWK_E_SIZE;
+    hipLaunchKernelGGL(adam_step_chunks_kernel, dim3((unsigned)rwk_ceil_div(n, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, param, a, grad_out, exp_avg, exp_avg_sq, (long long)n, lr, beta1, beta2,
+                       eps, weight_decay, (long long *)step_counters);
+    RWK_LAUNCH_CHECK();
     return RWK_OK;
 }
 

@@ -47,9 +47,30 @@ class FlatAdam:
         self.bucket.zero()
 
     @torch.no_grad()
-    def step(self):
+    def step(self, gather: bool = False):
+        """One Adam update from ``bucket.flat``.  ``gather=True``: take the gradients from the parameters'
+        ``.grad`` tensors instead (after ``bucket.release()`` and a backward pass, without ``bucket.gather()``)
+        and fill ``bucket.flat`` on the way: one launch for a single-process step."""
         lib = _lib.load()
         dev = self.flat_param.device
+        params = self.bucket.params
+        if gather and len(params) > 16:
+            self.bucket.gather()
+            gather = False
+        if gather:
+            import ctypes
+            grads = [None if p.grad is None else p.grad.detach().reshape(-1).contiguous().float() for p in params]
+            n = len(grads)
+            srcs = (ctypes.c_void_p * n)(*[None if g is None else g.data_ptr() for g in grads])
+            sizes = (ctypes.c_int64 * n)(*[p.numel() for p in params])
+            with torch.cuda.device(dev):
+                _lib.check(lib.rwk_adam_step_chunks(
+                    self.flat_param.data_ptr(), srcs, sizes, n, self.bucket.flat.data_ptr(), self.exp_avg.data_ptr(),
+                    self.exp_avg_sq.data_ptr(), self.flat_param.numel(), self.lr.data_ptr(), self.betas[0],
+                    self.betas[1], self.eps, self.weight_decay, self.step_counters.data_ptr(),
+                    _lib.current_stream(dev)), "rwk_adam_step_chunks")
+            self._keep = grads                     # the launch reads them asynchronously
+            return
         _lib.check(lib.rwk_adam_step(self.flat_param.data_ptr(), self.bucket.flat.data_ptr(),
                                      self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.flat_param.numel(),
                                      self.lr.data_ptr(), self.betas[0], self.betas[1], self.eps, self.weight_decay,

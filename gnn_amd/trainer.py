@@ -3,8 +3,8 @@
 ``train()`` in the reference is: ``optimizer.zero_grad()``, ``model(adj, features, graph_indicator)``,
 ``F.cross_entropy``, ``backward()``, ``optimizer.step()``.  On an MI355X the kernels of one such step on a
 1024-graph batch take about 0.2 ms, less than the host needs to launch them one by one, so ``Trainer`` offers
-the same step (a) eagerly and (b) captured once per batch into two HIP graphs (forward+backward, optimiser)
-that are replayed every epoch; batches are reused every epoch in the reference (``main.py:70-72,103-106``),
+the same step (a) eagerly and (b) captured once per batch into a HIP graph (two under data parallelism:
+forward+backward and optimiser, with the gradient all-reduce between them) that is replayed every epoch; batches are reused every epoch in the reference (``main.py:70-72,103-106``),
 which is what makes capture worthwhile.  Gradients live in one flat bucket (one all-reduce under data
 parallelism, one Adam launch).  The dropout generator's state lives on the device, so every replay draws
 fresh masks.
@@ -42,6 +42,8 @@ class Trainer:
             self.opt = torch.optim.Adam(model.parameters(), lr=lr, capturable=True, foreach=True)
         # F.cross_entropy(output, y) of main.py:85, one launch each way (gnn_amd.losses) or torch's own kernels
         self.loss_fn = cross_entropy if fused_loss else F.cross_entropy
+        # one process, flat optimiser: the gradient gather rides in the Adam launch
+        self.fused_gather = world == 1 and optimizer == "flat"
         self.loss = None
         # d(loss)/d(loss) = 1, kept resident: backward() would otherwise launch a fill for it every step
         self._one = torch.ones((), dtype=torch.float32, device=self.feats.device)
@@ -53,13 +55,20 @@ class Trainer:
         out = self.model(self.adj, self.feats, self.gi)
         self.loss = self.loss_fn(out, self.y)
         self.loss.backward(self._one)
-        self.bucket.gather()             # per-parameter gradients -> the flat bucket, one launch
+        if not self.fused_gather:
+            self.bucket.gather()         # per-parameter gradients -> the flat bucket, one launch
 
     def step_eager(self):
         self.fwd_bwd()
         if self.world > 1:
             self.bucket.all_reduce()
-        self.opt.step()
+        self._opt_step()
+
+    def _opt_step(self):
+        if self.fused_gather:
+            self.opt.step(gather=True)
+        else:
+            self.opt.step()
 
     def capture(self):
         """Capture forward+backward and the Adam update as two HIP graphs; the (tiny) gradient all-reduce
@@ -78,12 +87,15 @@ class Trainer:
         self.g_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_fb):
             self.fwd_bwd()
-        self.g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_opt):
-            self.opt.step()
+            if self.world == 1:          # nothing happens between backward and the update: one graph
+                self._opt_step()
+        if self.world > 1:
+            self.g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_opt):
+                self._opt_step()
 
     def step_graph(self):
         self.g_fb.replay()
         if self.world > 1:
             self.bucket.all_reduce()
-        self.g_opt.replay()
+            self.g_opt.replay()

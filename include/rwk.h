@@ -297,6 +297,15 @@ int rwk_adam_step(float *param, const float *grad, float *exp_avg, float *exp_av
                   const float *lr, float beta1, float beta2, float eps, float weight_decay,
                   int64_t *step_counters, rwk_stream_t stream);
 
+/* The same update with the gradient read from n_chunks <= 16 separate tensors (srcs[k]: sizes[k] floats, NULL =
+ * zeros; sum of sizes = n) in the order of the flat parameter buffer: rwk_gather_chunks and rwk_adam_step in
+ * one launch, for a single process (no all-reduce between the two).  grad_out (n floats) receives the flat
+ * gradient when not NULL.  More than 16 chunks: RWK_E_UNSUPPORTED (gather first). */
+int rwk_adam_step_chunks(float *param, const float *const *srcs, const int64_t *sizes, int64_t n_chunks,
+                         float *grad_out, float *exp_avg, float *exp_avg_sq, int64_t n, const float *lr,
+                         float beta1, float beta2, float eps, float weight_decay, int64_t *step_counters,
+                         rwk_stream_t stream);
+
 /* Test hook: writes the keep-mask exactly as the fused kernels draw it, one byte per element,
  * shape (L, H, S, N), for the {seed, offset} in rng. */
 int rwk_dropout_mask(const uint64_t *rng, int64_t n, int64_t h, int64_t s, int64_t max_step,

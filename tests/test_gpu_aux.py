@@ -61,7 +61,9 @@ def test_projection_forward_backward(n, f, d, dev):
     assert rel_err(d_feat.cpu().numpy(), fd.grad.cpu().numpy()) < 1e-5
 
 
-def test_flat_adam_matches_torch_adam(dev):
+@pytest.mark.parametrize("gather", [False, True])
+def test_flat_adam_matches_torch_adam(gather, dev):
+    """gather=True: the gradients are read from the parameters' own .grad tensors inside the Adam launch."""
     from gnn_amd.dp import FlatGradBucket
     from gnn_amd.optim import FlatAdam
     torch.manual_seed(0)
@@ -77,9 +79,16 @@ def test_flat_adam_matches_torch_adam(dev):
         opt_a.zero_grad()
         F.mse_loss(net_a(x), y).backward()
         opt_a.step()
-        opt_b.zero_grad()
-        F.mse_loss(net_b(x), y).backward()
-        opt_b.step()
+        if gather:
+            bucket.release()
+            F.mse_loss(net_b(x), y).backward()
+            grads = [p.grad.reshape(-1) for p in net_b.parameters()]
+            opt_b.step(gather=True)
+            assert torch.equal(bucket.flat, torch.cat(grads))
+        else:
+            opt_b.zero_grad()
+            F.mse_loss(net_b(x), y).backward()
+            opt_b.step()
     for pa, pb in zip(net_a.parameters(), net_b.parameters()):
         assert rel_err(pb.detach().cpu().numpy(), pa.detach().cpu().numpy()) < 1e-5
     assert int(opt_b.step_counters[0].item()) == 25
