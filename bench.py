@@ -365,7 +365,7 @@ def main():
             traffic = load_traffic(args.config, 1)
             result["kernels"] = kern
             result["roofline"] = roofline_of(kern, dom, traffic.get(dom, {}).get("hbm_bytes"))
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(batch, hp, args.cpu_sample_graphs)
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -31,7 +31,7 @@ class Trainer:
     """
 
     def __init__(self, model, batch_t, world: int = 1, optimizer: str = "flat", lr: float = 1e-2,
-                 fused_loss: bool = True):
+                 fused_loss: bool = True, capture_error_mode: str = None):
         self.model = model
         self.adj, self.feats, self.gi, self.y = batch_t
         self.bucket = FlatGradBucket(model)
@@ -44,6 +44,9 @@ class Trainer:
         self.loss_fn = cross_entropy if fused_loss else F.cross_entropy
         # one process, flat optimiser: the gradient gather rides in the Adam launch
         self.fused_gather = world == 1 and optimizer == "flat"
+        # Under data parallelism the collective library's watchdog thread polls events while the step is being
+        # captured; "thread_local" keeps its calls from invalidating the capture.
+        self.capture_error_mode = capture_error_mode or ("thread_local" if world > 1 else "global")
         self.loss = None
         # d(loss)/d(loss) = 1, kept resident: backward() would otherwise launch a fill for it every step
         self._one = torch.ones((), dtype=torch.float32, device=self.feats.device)
@@ -85,13 +88,13 @@ class Trainer:
         # forked replay was seen to feed stale gradients to the random-walk layer).
         self.loss = None
         self.g_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fb):
+        with torch.cuda.graph(self.g_fb, capture_error_mode=self.capture_error_mode):
             self.fwd_bwd()
             if self.world == 1:          # nothing happens between backward and the update: one graph
                 self._opt_step()
         if self.world > 1:
             self.g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_opt):
+            with torch.cuda.graph(self.g_opt, capture_error_mode=self.capture_error_mode):
                 self._opt_step()
 
     def step_graph(self):

@@ -94,7 +94,7 @@ def test_flat_adam_matches_torch_adam(gather, dev):
     assert int(opt_b.step_counters[0].item()) == 25
 
 
-def _trainer(c, hp, dev, seed=99):
+def _trainer(c, hp, dev, seed=99, world=1, **kw):
     import bench
     from gnn_amd import RW_NN
     torch.manual_seed(1)
@@ -103,15 +103,20 @@ def _trainer(c, hp, dev, seed=99):
     m.load_state_dict(c.torch_state())
     m.train()
     m.seed_dropout(seed)
-    return bench.Trainer(m, c.torch_inputs(dev), 1)
+    return bench.Trainer(m, c.torch_inputs(dev), world, **kw)
 
 
-def test_graph_replay_trains_like_eager(dev):
-    """Without dropout the captured step and the eager step follow the same trajectory."""
+@pytest.mark.parametrize("world", [1, 2])
+def test_graph_replay_trains_like_eager(world, dev):
+    """Without dropout the captured step and the eager step follow the same trajectory.  world = 2 takes the
+    data-parallel shape of the step (gradient gather, a slot for the all-reduce - a no-op without a process
+    group - and the optimiser in a second graph) on one device."""
     c = GoldenCase("mutag_b0")
     hp = dict(c.hp, dropout=0.0)
-    eager, graph = _trainer(c, hp, dev), _trainer(c, hp, dev)
+    eager, graph = _trainer(c, hp, dev, world=world), _trainer(c, hp, dev, world=world)
+    assert (graph.g_opt is None)
     graph.capture()                      # runs 3 eager warm-up steps, then captures
+    assert (graph.g_opt is None) == (world == 1)
     for _ in range(3):
         eager.step_eager()
     for _ in range(5):
@@ -125,7 +130,8 @@ def test_graph_replay_trains_like_eager(dev):
 def test_graph_replay_draws_fresh_dropout_masks(dev):
     """The dropout offset lives on the device: every replay of the captured step advances it."""
     c = GoldenCase("mutag_b0")
-    graph = _trainer(c, dict(c.hp, dropout=0.2), dev)
+    # captured in the mode the data-parallel runs use (the watchdog thread of the collective library is alive then)
+    graph = _trainer(c, dict(c.hp, dropout=0.2), dev, capture_error_mode="thread_local")
     graph.capture()
     offsets, losses = [], []
     for _ in range(5):
