@@ -265,11 +265,24 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # RWK_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share devices,
+    # the all-reduce goes through the host); the measured runs use nccl (= RCCL), one rank per GPU.
+    if os.environ.get("RWK_BENCH_TRACE"):            # hang diagnosis: dump every thread's stack after N seconds
+        import faulthandler
+        os.makedirs("gpurun_out", exist_ok=True)
+        faulthandler.dump_traceback_later(int(os.environ["RWK_BENCH_TRACE"]),
+                                          file=open("gpurun_out/trace_rank%d.txt" % rank, "w"), exit=True)
+    backend = os.environ.get("RWK_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from gnn_amd import RW_NN
     from gnn_amd.dp import broadcast_parameters
@@ -305,7 +318,7 @@ def main():
     model.train()
     model.seed_dropout(1234 + rank)
     broadcast_parameters(model)
-    tr = Trainer(model, batch_t, world, args.optimizer)
+    tr = Trainer(model, batch_t, world, args.optimizer, sync_before_all_reduce=backend != "nccl")
     if args.mode == "graph":
         tr.capture()
         step = tr.step_graph

@@ -31,7 +31,7 @@ class Trainer:
     """
 
     def __init__(self, model, batch_t, world: int = 1, optimizer: str = "flat", lr: float = 1e-2,
-                 fused_loss: bool = True, capture_error_mode: str = None):
+                 fused_loss: bool = True, capture_error_mode: str = None, sync_before_all_reduce: bool = False):
         self.model = model
         self.adj, self.feats, self.gi, self.y = batch_t
         self.bucket = FlatGradBucket(model)
@@ -44,6 +44,9 @@ class Trainer:
         self.loss_fn = cross_entropy if fused_loss else F.cross_entropy
         # one process, flat optimiser: the gradient gather rides in the Adam launch
         self.fused_gather = world == 1 and optimizer == "flat"
+        # gloo's all-reduce of a device tensor was seen to hang when the device still has queued work (two ranks on
+        # one GPU, with or without graphs); rehearsals on that backend wait for the device first.  RCCL runs do not.
+        self.sync_before_all_reduce = sync_before_all_reduce
         # Under data parallelism the collective library's watchdog thread polls events while the step is being
         # captured; "thread_local" keeps its calls from invalidating the capture.
         self.capture_error_mode = capture_error_mode or ("thread_local" if world > 1 else "global")
@@ -64,8 +67,13 @@ class Trainer:
     def step_eager(self):
         self.fwd_bwd()
         if self.world > 1:
-            self.bucket.all_reduce()
+            self._all_reduce()
         self._opt_step()
+
+    def _all_reduce(self):
+        if self.sync_before_all_reduce:
+            torch.cuda.current_stream().synchronize()
+        self.bucket.all_reduce()
 
     def _opt_step(self):
         if self.fused_gather:
@@ -100,5 +108,5 @@ class Trainer:
     def step_graph(self):
         self.g_fb.replay()
         if self.world > 1:
-            self.bucket.all_reduce()
+            self._all_reduce()
             self.g_opt.replay()
