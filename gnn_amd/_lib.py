@@ -103,5 +103,31 @@ def ptr(t):
 
 
 def current_stream(device):
+    """Raw ``hipStream_t`` of torch's current stream on ``device`` (no Stream object is built: this is called
+    several times per training step)."""
     import torch
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:
+        return raw(idx)
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def device_guard(device):
+    """``torch.cuda.device(device)``, or a no-op context when ``device`` is already the current one (the usual
+    case: one process per GPU; autograd's worker thread runs a backward on the device of its inputs)."""
+    import torch
+    if device.index is None or torch.cuda.current_device() == device.index:
+        return _NO_GUARD
+    return torch.cuda.device(device)

@@ -54,6 +54,7 @@ class FlatGradBucket:
         dev, dtype = self.params[0].device, self.params[0].dtype
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, dtype=dtype, device=dev)
+        self._avg_ok = None                # whether the backend accepted ReduceOp.AVG (unknown until first use)
         off = 0
         for p in self.params:
             n = p.numel()
@@ -80,7 +81,7 @@ class FlatGradBucket:
             n = len(grads)
             srcs = (ctypes.c_void_p * n)(*[None if g is None else g.data_ptr() for g in grads])
             sizes = (ctypes.c_int64 * n)(*[p.numel() for p in self.params])
-            with torch.cuda.device(self.flat.device):
+            with _lib.device_guard(self.flat.device):
                 _lib.check(lib.rwk_gather_chunks(srcs, sizes, n, self.flat.data_ptr(),
                                                  _lib.current_stream(self.flat.device)), "rwk_gather_chunks")
             self._keep = grads                     # the launch reads them asynchronously
@@ -101,6 +102,16 @@ class FlatGradBucket:
         world = dist.get_world_size(group)
         if world == 1:
             return
+        if average and self.flat.is_cuda and dist.get_backend(group) == "nccl" and self._avg_ok is not False:
+            # RCCL averages inside the collective: no separate division launch
+            try:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
+                self._avg_ok = True
+                return
+            except (RuntimeError, ValueError):
+                if self._avg_ok:                      # it worked before: a real failure, not a missing feature
+                    raise
+                self._avg_ok = False
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         if average:
             self.flat.div_(world)

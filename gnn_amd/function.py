@@ -62,7 +62,7 @@ class _RWKernelLayer(torch.autograd.Function):
                 "the HIP kernels cover hidden_graphs <= 64, hidden_dim <= 64, max_step <= 4 "
                 f"(got {n_hidden}, {d}, {steps})")
         drop = float(drop_p) if (drop_p and rng_state is not None) else 0.0
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             stream = _lib.current_stream(dev)
             adj_hidden_c = adj_hidden.detach().contiguous()
             feat_c = features_hidden.detach().contiguous()
@@ -111,7 +111,7 @@ class _RWKernelLayer(torch.autograd.Function):
         n = st.n
         stream_len = choose_stream_len(n, d, n_hidden, s, steps, backward=True)
         dev = xs.device
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             stream = _lib.current_stream(dev)
             d_k = d_k.contiguous().float()
             dx = torch.empty_like(xs)

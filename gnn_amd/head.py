@@ -34,7 +34,7 @@ class _FusedHead(torch.autograd.Function):
                              % (tuple(k.shape),))
         drop = float(drop_p) if (training and drop_p and rng_state is not None) else 0.0
         needs_grad = any(ctx.needs_input_grad[:7])
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             stream = _lib.current_stream(dev)
             kc = k.detach().contiguous()
             tensors = [t.detach().contiguous() for t in (bn_w, bn_b, w1, b1, w2, b2)]
@@ -65,7 +65,7 @@ class _FusedHead(torch.autograd.Function):
         g, c = kc.shape
         p, nc = w1c.shape[0], w2c.shape[0]
         dev = kc.device
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             stream = _lib.current_stream(dev)
             d_out = d_out.contiguous().float()
             nv = lib.rwk_head_grad_size(c, p, nc)

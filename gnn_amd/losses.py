@@ -22,7 +22,7 @@ class _CrossEntropy(torch.autograd.Function):
             raise TypeError("labels must be int64")
         g, nc = scores.shape
         dev = scores.device
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             x = scores.detach().contiguous().float()
             y = labels.contiguous()
             loss = torch.empty((), dtype=torch.float32, device=dev)
@@ -38,7 +38,7 @@ class _CrossEntropy(torch.autograd.Function):
         x, y = ctx.saved_tensors
         g, nc = x.shape
         dev = x.device
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             d_loss = d_loss.contiguous().float()
             d_x = torch.empty_like(x)
             _lib.check(lib.rwk_cross_entropy_backward(x.data_ptr(), y.data_ptr(), g, nc, d_loss.data_ptr(),

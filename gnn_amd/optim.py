@@ -59,11 +59,13 @@ class FlatAdam:
             gather = False
         if gather:
             import ctypes
-            grads = [None if p.grad is None else p.grad.detach().reshape(-1).contiguous().float() for p in params]
+            grads = [p.grad for p in params]
+            grads = [g if g is None or (g.dtype is torch.float32 and g.is_contiguous())
+                     else g.detach().contiguous().float() for g in grads]
             n = len(grads)
             srcs = (ctypes.c_void_p * n)(*[None if g is None else g.data_ptr() for g in grads])
             sizes = (ctypes.c_int64 * n)(*[p.numel() for p in params])
-            with torch.cuda.device(dev):
+            with _lib.device_guard(dev):
                 _lib.check(lib.rwk_adam_step_chunks(
                     self.flat_param.data_ptr(), srcs, sizes, n, self.bucket.flat.data_ptr(), self.exp_avg.data_ptr(),
                     self.exp_avg_sq.data_ptr(), self.flat_param.numel(), self.lr.data_ptr(), self.betas[0],
