@@ -226,19 +226,21 @@ fused_reduce_kernel(const float *__restrict__ k_partials, const int *__restrict_
     const int g = (int)(t / lh), col = (int)(t % lh);
     const int c_first = seg_ptr[g] / stream_len;
     const int c_last = (seg_ptr[g + 1] - 1) / stream_len;
-    // slots are added in stream order; four loads are requested at a time so that their latencies overlap
+    // slots are added in stream order; sixteen loads are requested at a time (at clamped indices) so that their
+    // latencies overlap: a graph of a few hundred nodes is covered by one or two such groups
     const float *src = k_partials + (size_t)g * lh + col;
     float acc = 0.f;
-    int c = c_first;
-    for (; c + 3 <= c_last; c += 4) {
-        const float a0 = src[(size_t)c * lh], a1 = src[(size_t)(c + 1) * lh], a2 = src[(size_t)(c + 2) * lh],
-                    a3 = src[(size_t)(c + 3) * lh];
-        acc += a0;
-        acc += a1;
-        acc += a2;
-        acc += a3;
+    for (int c0 = c_first; c0 <= c_last; c0 += 16) {
+        float a[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int c = c0 + u;
+            a[u] = src[(size_t)(c <= c_last ? c : c_last) * lh];
+            if (c > c_last) a[u] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += a[u];
     }
-    for (; c <= c_last; ++c) acc += src[(size_t)c * lh];
     acc *= scale;
     if (normalize) acc /= counts_f32[g];
     k[t] = acc;
