@@ -5,11 +5,11 @@
 // a GEMM library spends ~0.7 ms on the N-long weight-gradient reduction, the kernels here stream it
 // at HBM rate: forward reads N*F and writes N*D floats; backward reads 2*N*D + N*F floats and
 // writes per-workgroup partial sums of (dW | db) which rwk_reduce_rows adds in a fixed order.
-#include "rwk_common.h"
+#include "rwk_project_body.h"
 
 namespace {
 
-constexpr int kBlock = 256;
+constexpr int kBlock = kProjectBlock;
 
 // one thread per (node, output channel); 32-bit index arithmetic (n * d < 2^31 is checked by the launcher)
 __global__ void __launch_bounds__(kBlock)
@@ -26,95 +26,20 @@ project_forward_kernel(const float *__restrict__ feat, const float *__restrict__
     x0[t] = 1.0f / (1.0f + expf(-acc));
 }
 
-// hidden_dim 4 (the reference's default): one thread per node, one 16-byte store per row
 template <int FP>
 __global__ void __launch_bounds__(kBlock)
 project_forward4_kernel(const float *__restrict__ feat, const float *__restrict__ w, const float *__restrict__ b,
                         int n, int f, float *__restrict__ x0) {
-    const int node = blockIdx.x * kBlock + threadIdx.x;
-    if (node >= n) return;
-    float fr[FP];
-#pragma unroll
-    for (int k = 0; k < FP; ++k) fr[k] = feat[(size_t)node * f + (k < f ? k : f - 1)];
-    float o[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        float acc = b[c];
-#pragma unroll
-        for (int k = 0; k < FP; ++k)
-            if (k < f) acc = fmaf(fr[k], w[c * f + k], acc);
-        o[c] = 1.0f / (1.0f + expf(-acc));
-    }
-    reinterpret_cast<float4 *>(x0)[node] = make_float4(o[0], o[1], o[2], o[3]);
+    project_forward4_body<FP>(blockIdx.x, feat, w, b, n, f, x0);
 }
 
-// Thread (slot, c): c = output channel, slot strides over nodes.  FP = padded input width.
-// partials row layout: [c * f + k] for dW (d*f values) then [d*f + c] for db.
 template <int FP>
 __global__ void __launch_bounds__(kBlock)
 project_backward_kernel(const float *__restrict__ dx0, const float *__restrict__ x0,
                         const float *__restrict__ feat, const float *__restrict__ w, long long n, int f, int d,
                         int dpad, float *__restrict__ partials, float *__restrict__ d_feat) {
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [FP + 1][kBlock]
-    const int tid = threadIdx.x;
-    const int c = tid % dpad;
-    const int slot = tid / dpad;
-    const int slots = kBlock / dpad;
-    const bool own = c < d;
-    float acc_w[FP];
-#pragma unroll
-    for (int k = 0; k < FP; ++k) acc_w[k] = 0.f;
-    float acc_b = 0.f;
-    float wr[FP];
-#pragma unroll
-    for (int k = 0; k < FP; ++k) wr[k] = (own && k < f) ? w[(size_t)c * f + k] : 0.f;
-    // uniform trip count so that the optional group sum sees every lane; the loads of four rounds are issued
-    // together (unconditional, at clamped indices), then the rounds are added in order
-    const long long per_round = (long long)gridDim.x * slots;
-    const long long rounds = (n + per_round - 1) / per_round;
-    const int cc = own ? c : d - 1;
-    for (long long r0 = 0; r0 < rounds; r0 += 4) {
-        float xv[4], dv[4], fr[4][FP];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long long node = (r0 + u) * per_round + (long long)blockIdx.x * slots + slot;
-            const long long nc = node < n ? node : n - 1;
-            xv[u] = x0[nc * d + cc];
-            dv[u] = dx0[nc * d + cc];
-#pragma unroll
-            for (int k = 0; k < FP; ++k) fr[u][k] = feat[nc * f + (k < f ? k : f - 1)];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (r0 + u >= rounds) break;                  // uniform
-            const long long node = (r0 + u) * per_round + (long long)blockIdx.x * slots + slot;
-            const bool valid = node < n && own;
-            const float dpre = valid ? dv[u] * xv[u] * (1.0f - xv[u]) : 0.f;
-            acc_b += dpre;
-#pragma unroll
-            for (int k = 0; k < FP; ++k) acc_w[k] = fmaf(dpre, (valid && k < f) ? fr[u][k] : 0.f, acc_w[k]);
-            if (d_feat != nullptr) {
-#pragma unroll
-                for (int k = 0; k < FP; ++k) {
-                    const float v = rwk_group_sum(dpre * wr[k], dpad);
-                    if (node < n && c == 0 && k < f) d_feat[node * f + k] = v;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < FP; ++k) lds[k * kBlock + tid] = acc_w[k];
-    lds[FP * kBlock + tid] = acc_b;
-    __syncthreads();
-    const int n_out = d * f + d;
-    float *out = partials + (size_t)blockIdx.x * n_out;
-    for (int o = tid; o < n_out; o += kBlock) {
-        int cc, row;
-        if (o < d * f) { cc = o / f; row = o % f; } else { cc = o - d * f; row = FP; }
-        float acc = 0.f;
-        for (int q = 0; q < slots; ++q) acc += lds[row * kBlock + q * dpad + cc];
-        out[o] = acc;
-    }
+    project_backward_body<FP>(blockIdx.x, gridDim.x, lds, dx0, x0, feat, w, n, f, d, dpad, partials, d_feat);
 }
 
 // Level 1: workgroup (bx, by) owns 64 columns and the rows [by*rows_per_block, (by+1)*rows_per_block);

@@ -22,6 +22,9 @@ from .structure import GraphStructure
 __all__ = ["rw_kernel_layer", "rw_kernel_layer_projected", "choose_stream_len", "FUSED_PROJECTION_MAX_INPUT_DIM"]
 
 FUSED_PROJECTION_MAX_INPUT_DIM = 8
+#: launch the hidden-graph kernels together with the projection kernels they are independent of (one launch
+#: instead of two, forward and backward); False keeps the stand-alone launches (tests compare the two)
+MERGED_LAUNCHES = True
 
 def choose_stream_len(n_nodes: int, hidden_dim: int, n_hidden: int, size_hidden: int, max_step: int,
                       backward: bool = False) -> int:
@@ -69,20 +72,27 @@ class _RWKernelLayer(torch.autograd.Function):
             xs = torch.empty((steps, n, d), dtype=torch.float32, device=dev)
             inp_c = inp.detach().contiguous()
             w_c = None
-            if projected:                                                        # model.py:43
-                w_c = fc_weight.detach().contiguous()
-                _lib.check(lib.rwk_project_forward(inp_c.data_ptr(), w_c.data_ptr(),
-                                                   fc_bias.detach().contiguous().data_ptr(), n, inp_c.shape[1], d,
-                                                   xs.data_ptr(), stream), "rwk_project_forward")
-            else:
-                torch.sigmoid(inp_c, out=xs[0])
             z = torch.empty((steps, n_hidden, s, d), dtype=torch.float32, device=dev)
             ah = torch.empty((n_hidden, s, s), dtype=torch.float32, device=dev)
             rng_used = torch.empty(2, dtype=torch.int64, device=dev) if drop else None
-            _lib.check(lib.rwk_hidden_forward(_lib.ptr(adj_hidden_c), feat_c.data_ptr(), n_hidden, s, d, steps,
-                                              ah.data_ptr(), z.data_ptr(),
-                                              _lib.ptr(rng_state) if drop else None, _lib.ptr(rng_used), stream),
-                       "rwk_hidden_forward")
+            rng_in = _lib.ptr(rng_state) if drop else None
+            if projected and d == 4 and MERGED_LAUNCHES:                         # model.py:39-43,56 in one launch
+                w_c = fc_weight.detach().contiguous()
+                _lib.check(lib.rwk_project_hidden_forward(
+                    inp_c.data_ptr(), w_c.data_ptr(), fc_bias.detach().contiguous().data_ptr(), n, inp_c.shape[1], d,
+                    xs.data_ptr(), _lib.ptr(adj_hidden_c), feat_c.data_ptr(), n_hidden, s, steps, ah.data_ptr(),
+                    z.data_ptr(), rng_in, _lib.ptr(rng_used), stream), "rwk_project_hidden_forward")
+            else:
+                if projected:                                                    # model.py:43
+                    w_c = fc_weight.detach().contiguous()
+                    _lib.check(lib.rwk_project_forward(inp_c.data_ptr(), w_c.data_ptr(),
+                                                       fc_bias.detach().contiguous().data_ptr(), n, inp_c.shape[1],
+                                                       d, xs.data_ptr(), stream), "rwk_project_forward")
+                else:
+                    torch.sigmoid(inp_c, out=xs[0])
+                _lib.check(lib.rwk_hidden_forward(_lib.ptr(adj_hidden_c), feat_c.data_ptr(), n_hidden, s, d, steps,
+                                                  ah.data_ptr(), z.data_ptr(), rng_in, _lib.ptr(rng_used), stream),
+                           "rwk_hidden_forward")
             for i in range(1, steps):
                 st.spmm(xs[i - 1], xs[i])                                        # model.py:55
             stream_len = choose_stream_len(n, d, n_hidden, s, steps)
@@ -137,20 +147,29 @@ class _RWKernelLayer(torch.autograd.Function):
                                                     dz.data_ptr(), stream), "rwk_reduce_rows_to32")
             d_adj = torch.empty_like(adj_hidden_c)
             d_feat = torch.empty((n_hidden, s, d), dtype=torch.float32, device=dev)
-            _lib.check(lib.rwk_hidden_backward(_lib.ptr(adj_hidden_c), ah.data_ptr(), z.data_ptr(),
-                                               dz.data_ptr(), dz_rows, n_hidden, s, d, steps,
-                                               _lib.ptr(d_adj), d_feat.data_ptr(), stream),
-                       "rwk_hidden_backward")
             x0 = xs[0]
             d_w = d_b = None
+            merged = projected and MERGED_LAUNCHES
+            if not merged:
+                _lib.check(lib.rwk_hidden_backward(_lib.ptr(adj_hidden_c), ah.data_ptr(), z.data_ptr(),
+                                                   dz.data_ptr(), dz_rows, n_hidden, s, d, steps,
+                                                   _lib.ptr(d_adj), d_feat.data_ptr(), stream),
+                           "rwk_hidden_backward")
             if projected:
                 f = feats.shape[1]
                 blocks = lib.rwk_project_backward_blocks(n, d)
                 partials = torch.empty((blocks, d * f + d), dtype=torch.float32, device=dev)
                 d_inp = torch.empty_like(feats) if ctx.needs_input_grad[0] else None
-                _lib.check(lib.rwk_project_backward(dx.data_ptr(), x0.data_ptr(), feats.data_ptr(), w_c.data_ptr(),
-                                                    n, f, d, partials.data_ptr(), _lib.ptr(d_inp), stream),
-                           "rwk_project_backward")
+                if merged:                                                       # both backward kernels, one launch
+                    _lib.check(lib.rwk_project_hidden_backward(
+                        dx.data_ptr(), x0.data_ptr(), feats.data_ptr(), w_c.data_ptr(), n, f, d, partials.data_ptr(),
+                        _lib.ptr(d_inp), _lib.ptr(adj_hidden_c), ah.data_ptr(), z.data_ptr(), dz.data_ptr(), dz_rows,
+                        n_hidden, s, steps, _lib.ptr(d_adj), d_feat.data_ptr(), stream),
+                        "rwk_project_hidden_backward")
+                else:
+                    _lib.check(lib.rwk_project_backward(dx.data_ptr(), x0.data_ptr(), feats.data_ptr(),
+                                                        w_c.data_ptr(), n, f, d, partials.data_ptr(),
+                                                        _lib.ptr(d_inp), stream), "rwk_project_backward")
                 wb = _reduce_rows(lib, partials, stream)
                 d_w = wb[:d * f].view(d, f)
                 d_b = wb[d * f:]

@@ -267,6 +267,24 @@ int rwk_project_backward(const float *dx0, const float *x0, const float *feature
                          const float *weight, int64_t n, int64_t f, int64_t d, float *partials,
                          float *d_features, rwk_stream_t stream);
 
+/* rwk_hidden_forward and rwk_project_forward in ONE launch (model.py:39-43,56: neither depends on the other),
+ * for hidden_dim d = 4 and f <= 8 input features (RWK_E_UNSUPPORTED otherwise: launch the two separately).
+ * Arguments and results as the two stand-alone entry points. */
+int rwk_project_hidden_forward(const float *features, const float *weight, const float *bias, int64_t n,
+                               int64_t f, int64_t d, float *x0, const float *adj_hidden,
+                               const float *features_hidden, int64_t h, int64_t s, int64_t max_step,
+                               float *ah, float *z, uint64_t *rng_state, uint64_t *rng_used,
+                               rwk_stream_t stream);
+
+/* rwk_hidden_backward and rwk_project_backward in ONE launch (their inputs, the reduced dZ partials and
+ * dx[0] after the SpMM chain, are both ready at that point of the backward pass); f <= 8, d <= 64. */
+int rwk_project_hidden_backward(const float *dx0, const float *x0, const float *features,
+                                const float *weight, int64_t n, int64_t f, int64_t d, float *partials,
+                                float *d_features, const float *adj_hidden, const float *ah,
+                                const float *z, const float *dz_partials, int64_t n_partials, int64_t h,
+                                int64_t s, int64_t max_step, float *d_adj_hidden,
+                                float *d_features_hidden, rwk_stream_t stream);
+
 /* out[v] = sum_p in[p, v], rows added in a fixed order (p > 32: 32 row blocks of ceil(p/32) rows,
  * each summed by 4 interleaved slices, then the 32 block sums in index order; v <= 64 columns: one
  * launch, interleaved lanes per column and a halving tree), so the result is bitwise

@@ -160,6 +160,31 @@ def _float64_port_grads(c):
     return grads
 
 
+@pytest.mark.parametrize("name", ["mutag_b0", "mutag_b2_norm", "step1", "tiny_graphs_step4"])
+def test_merged_launches_equal_separate_launches(name, dev):
+    """The hidden-graph kernels ride in the projection kernels' launches (forward and backward); with the merge
+    switched off the stand-alone kernels run: same bits in K and in every gradient."""
+    import gnn_amd.function as fn
+    c = GoldenCase(name)
+    adj, feats, gi, _ = c.torch_inputs(dev)
+    dk = torch.from_numpy(c["dk"]).to(dev)
+    runs = []
+    try:
+        for merged in (True, False):
+            fn.MERGED_LAUNCHES = merged
+            m = _model_for(c, dev)
+            fe = feats.clone().requires_grad_(True)
+            k = m.rw_features(adj, fe, gi)
+            k.backward(dk)
+            grads = [p.grad for p in (m.adj_hidden, m.features_hidden, m.fc.weight, m.fc.bias) if p.grad is not None]
+            runs.append([k.detach(), fe.grad] + grads)
+    finally:
+        fn.MERGED_LAUNCHES = True
+    assert len(runs[0]) == len(runs[1])
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+
+
 def test_backward_is_bitwise_reproducible(dev):
     c = GoldenCase("mutag_b0")
     m = _model_for(c, dev)
