@@ -29,6 +29,7 @@ SIGNATURES = {
     "rwk_spmm_csr": (c_int, [_P, _P, _P, _I64, _I64, _P, _P, c_int, c_int32, _P, _I64, c_int32, _P]),
     "rwk_csr_compact": (c_int, [_P, _P, _P, _I64, _P, _P, _P]),
     "rwk_spmm_csr_compact": (c_int, [_P, _P, _P, _I64, _I64, _P, _P, c_int, _P]),
+    "rwk_spmm_tile_reduce_rows": (c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, c_int, _P, _I64, _I64, _P, _P]),
     "rwk_hidden_forward": (c_int, [_P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P]),
     "rwk_hidden_backward": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P]),
     "rwk_fused_n_streams": (_I64, [_I64, _I64]),

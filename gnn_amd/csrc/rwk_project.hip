@@ -6,6 +6,7 @@
 // at HBM rate: forward reads N*F and writes N*D floats; backward reads 2*N*D + N*F floats and
 // writes per-workgroup partial sums of (dW | db) which rwk_reduce_rows adds in a fixed order.
 #include "rwk_project_body.h"
+#include "rwk_reduce_body.h"
 
 namespace {
 
@@ -42,34 +43,10 @@ project_backward_kernel(const float *__restrict__ dx0, const float *__restrict__
     project_backward_body<FP>(blockIdx.x, gridDim.x, lds, dx0, x0, feat, w, n, f, d, dpad, partials, d_feat);
 }
 
-// Level 1: workgroup (bx, by) owns 64 columns and the rows [by*rows_per_block, (by+1)*rows_per_block);
-// its 4 wavefronts ("slices") take every 4th row of that range, then the slices are added in slice order.
 __global__ void __launch_bounds__(kBlock)
 reduce_rows_level1_kernel(const float *__restrict__ in, long long p, long long v, int rows_per_block,
                           float *__restrict__ out) {
-    __shared__ float part[4][64];
-    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const long long col = (long long)blockIdx.x * 64 + lane;
-    const long long r0 = (long long)blockIdx.y * rows_per_block;
-    long long r1 = r0 + rows_per_block;
-    if (r1 > p) r1 = p;
-    float acc = 0.f;
-    if (col < v) {
-        long long r = r0 + slice;
-        for (; r + 12 < r1; r += 16) {                  // four rows in flight, added in row order
-            const float a0 = in[r * v + col], a1 = in[(r + 4) * v + col], a2 = in[(r + 8) * v + col],
-                        a3 = in[(r + 12) * v + col];
-            acc += a0;
-            acc += a1;
-            acc += a2;
-            acc += a3;
-        }
-        for (; r < r1; r += 4) acc += in[r * v + col];
-    }
-    part[slice][lane] = acc;
-    __syncthreads();
-    if (slice == 0 && col < v)
-        out[(long long)blockIdx.y * v + col] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    reduce_rows_level1_body(blockIdx.x, blockIdx.y, in, p, v, rows_per_block, out);
 }
 
 // Level 2: out[col] = sum of p <= 32 rows in index order.
@@ -90,7 +67,7 @@ reduce_rows_final_kernel(const float *__restrict__ in, int p, long long v, float
     out[col] = acc;
 }
 
-constexpr int kMaxFinalRows = 32;
+constexpr int kMaxFinalRows = kReduceMaxFinalRows;
 
 // Few columns (v <= 64) and up to a few thousand rows in ONE launch: a workgroup of 1024 threads gives every
 // column 1024/vp lanes (vp = v rounded up to a power of two); lane l adds rows l, l + lanes, ... in order (four

@@ -9,6 +9,7 @@
 //
 // HBM traffic per call (the figure the roofline uses): nnz*(4+4) + (n+1)*4 + 2*n*d*4 bytes.
 #include "rwk_common.h"
+#include "rwk_reduce_body.h"
 
 namespace {
 
@@ -99,10 +100,12 @@ constexpr int kLongRow = 64;
 // ---------------------------------------------------------------------------------------------------
 constexpr int kColBlock = 256;
 
+// bid / nblocks: this workgroup's index among the SpMM workgroups of the launch (they come first in a merged launch,
+// so the dispatch order, and with it the XCD a workgroup lands on, is that of a stand-alone launch)
 template <int VEC, bool ALIGNED, typename COLT, bool UNIT>
-__global__ void __launch_bounds__(kBlock)
-spmm_tile_kernel(const int32_t *__restrict__ crow, const COLT *__restrict__ col, const float *__restrict__ val,
-                 int n, int d, const float *__restrict__ x, float *__restrict__ y, int accumulate) {
+__device__ inline void spmm_tile_body(int bid, int nblocks, const int32_t *__restrict__ crow,
+                                      const COLT *__restrict__ col, const float *__restrict__ val, int n, int d,
+                                      const float *__restrict__ x, float *__restrict__ y, int accumulate) {
     constexpr int RPW = kBlock / VEC;                   // rows per workgroup = entry slots per pass
     constexpr int ET = kTileBytes / (16 * VEC);         // entries per LDS tile
     constexpr int PASSES = ET / RPW;
@@ -119,9 +122,8 @@ spmm_tile_kernel(const int32_t *__restrict__ crow, const COLT *__restrict__ col,
     // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give every XCD one contiguous
     // eighth of the row blocks, so that neighbouring blocks (rows of the same graph, which gather the same
     // x rows) meet in one L2.
-    const int per_xcd = gridDim.x / 8;
-    const int lb = (int)blockIdx.x < per_xcd * 8 ? ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8
-                                                 : (int)blockIdx.x;
+    const int per_xcd = nblocks / 8;
+    const int lb = bid < per_xcd * 8 ? (bid % 8) * per_xcd + bid / 8 : bid;
     const int r0 = lb * RPW;
     const int col_base = sizeof(COLT) == 2 ? (r0 & ~(kColBlock - 1)) : 0;
     const int nrows = n - r0 < RPW ? n - r0 : RPW;
@@ -250,30 +252,73 @@ spmm_tile_kernel(const int32_t *__restrict__ crow, const COLT *__restrict__ col,
     }
 }
 
+template <int VEC, bool ALIGNED, typename COLT, bool UNIT>
+__global__ void __launch_bounds__(kBlock)
+spmm_tile_kernel(const int32_t *__restrict__ crow, const COLT *__restrict__ col, const float *__restrict__ val,
+                 int n, int d, const float *__restrict__ x, float *__restrict__ y, int accumulate) {
+    spmm_tile_body<VEC, ALIGNED, COLT, UNIT>(blockIdx.x, gridDim.x, crow, col, val, n, d, x, y, accumulate);
+}
+
+// The tile SpMM and the first level of an independent row reduction in one launch: workgroups [0, spmm_blocks)
+// run the SpMM, the rest the reduction (red_bx column blocks x 32 row blocks).
+template <int VEC, bool ALIGNED, typename COLT, bool UNIT>
+__global__ void __launch_bounds__(kBlock)
+spmm_tile_reduce_kernel(const int32_t *__restrict__ crow, const COLT *__restrict__ col, const float *__restrict__ val,
+                        int n, int d, const float *__restrict__ x, float *__restrict__ y, int accumulate,
+                        int spmm_blocks, const float *__restrict__ red_in, long long red_p, long long red_v,
+                        int red_rows_per_block, int red_bx, float *__restrict__ red_out) {
+    if ((int)blockIdx.x < spmm_blocks) {
+        spmm_tile_body<VEC, ALIGNED, COLT, UNIT>(blockIdx.x, spmm_blocks, crow, col, val, n, d, x, y, accumulate);
+    } else {
+        const int r = (int)blockIdx.x - spmm_blocks;
+        reduce_rows_level1_body(r % red_bx, r / red_bx, red_in, red_p, red_v, red_rows_per_block, red_out);
+    }
+}
+
+struct ReduceJob {
+    const float *in;
+    long long p, v;
+    float *out32;
+};
+
 template <int VEC, typename COLT>
 int launch_tile(const int32_t *crow, const COLT *col, const float *val, int64_t n, int64_t d, const float *x,
-                float *y, int accumulate, hipStream_t stream) {
+                float *y, int accumulate, hipStream_t stream, const ReduceJob *job) {
     const bool aligned = (d == 4 * VEC) && ((((uintptr_t)x | (uintptr_t)y) & 15u) == 0);
-    const dim3 grid((unsigned)rwk_ceil_div(n, kBlock / VEC));
+    const unsigned spmm_blocks = (unsigned)rwk_ceil_div(n, kBlock / VEC);
+    if (job == nullptr) {
+        const dim3 grid(spmm_blocks);
 #define RWK_TILE(AL, UN)                                                                                        \
     hipLaunchKernelGGL((spmm_tile_kernel<VEC, AL, COLT, UN>), grid, dim3(kBlock), 0, stream, crow, col, val, (int)n, \
                        (int)d, x, y, accumulate)
-    if (val == nullptr) { if (aligned) RWK_TILE(true, true); else RWK_TILE(false, true); }
-    else { if (aligned) RWK_TILE(true, false); else RWK_TILE(false, false); }
+        if (val == nullptr) { if (aligned) RWK_TILE(true, true); else RWK_TILE(false, true); }
+        else { if (aligned) RWK_TILE(true, false); else RWK_TILE(false, false); }
 #undef RWK_TILE
+    } else {
+        const int red_bx = (int)rwk_ceil_div(job->v, 64);
+        const int rows_per_block = (int)rwk_ceil_div(job->p, kReduceMaxFinalRows);
+        const dim3 grid(spmm_blocks + (unsigned)red_bx * kReduceMaxFinalRows);
+#define RWK_TILE(AL, UN)                                                                                        \
+    hipLaunchKernelGGL((spmm_tile_reduce_kernel<VEC, AL, COLT, UN>), grid, dim3(kBlock), 0, stream, crow, col, val, \
+                       (int)n, (int)d, x, y, accumulate, (int)spmm_blocks, job->in, job->p, job->v, rows_per_block, \
+                       red_bx, job->out32)
+        if (val == nullptr) { if (aligned) RWK_TILE(true, true); else RWK_TILE(false, true); }
+        else { if (aligned) RWK_TILE(true, false); else RWK_TILE(false, false); }
+#undef RWK_TILE
+    }
     RWK_LAUNCH_CHECK();
     return RWK_OK;
 }
 
 template <typename COLT>
 int launch_tile_by_width(const int32_t *crow, const COLT *col, const float *val, int64_t n, int64_t d, const float *x,
-                         float *y, int accumulate, hipStream_t stream) {
+                         float *y, int accumulate, hipStream_t stream, const ReduceJob *job = nullptr) {
     const int vec = (int)((d + 3) / 4);
-    if (vec == 1) return launch_tile<1, COLT>(crow, col, val, n, d, x, y, accumulate, stream);
-    if (vec == 2) return launch_tile<2, COLT>(crow, col, val, n, d, x, y, accumulate, stream);
-    if (vec <= 4) return launch_tile<4, COLT>(crow, col, val, n, d, x, y, accumulate, stream);
-    if (vec <= 8) return launch_tile<8, COLT>(crow, col, val, n, d, x, y, accumulate, stream);
-    return launch_tile<16, COLT>(crow, col, val, n, d, x, y, accumulate, stream);
+    if (vec == 1) return launch_tile<1, COLT>(crow, col, val, n, d, x, y, accumulate, stream, job);
+    if (vec == 2) return launch_tile<2, COLT>(crow, col, val, n, d, x, y, accumulate, stream, job);
+    if (vec <= 4) return launch_tile<4, COLT>(crow, col, val, n, d, x, y, accumulate, stream, job);
+    if (vec <= 8) return launch_tile<8, COLT>(crow, col, val, n, d, x, y, accumulate, stream, job);
+    return launch_tile<16, COLT>(crow, col, val, n, d, x, y, accumulate, stream, job);
 }
 
 // col16[e] = col[e] - (row & ~255); flags[0] counts entries that do not fit, flags[1] values other than 1.0f
@@ -375,4 +420,24 @@ extern "C" int rwk_spmm_csr_compact(const int32_t *crow, const int16_t *col16, c
     if (n <= 0 || n >= 0x7FFFFFFFll || d <= 0) return RWK_E_SIZE;
     if (d > 64) return RWK_E_UNSUPPORTED;
     return launch_tile_by_width<int16_t>(crow, col16, val, n, d, x, y, accumulate, (hipStream_t)stream);
+}
+
+extern "C" int rwk_spmm_tile_reduce_rows(const int32_t *crow, const int32_t *col, const int16_t *col16, const float *val,
+                                         int64_t n, int64_t d, const float *x, float *y, int accumulate,
+                                         const float *red_in, int64_t red_p, int64_t red_v, float *red_out32,
+                                         rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(crow);
+    RWK_REQUIRE_PTR(x);
+    RWK_REQUIRE_PTR(y);
+    RWK_REQUIRE_PTR(red_in);
+    RWK_REQUIRE_PTR(red_out32);
+    if (col == nullptr && col16 == nullptr) return RWK_E_NULL;
+    if (n <= 0 || n >= 0x7FFFFFFFll || d <= 0) return RWK_E_SIZE;
+    if (d > 64) return RWK_E_UNSUPPORTED;
+    if (red_p <= kReduceMaxFinalRows || red_v <= 0 || red_v >= 0x7FFFFFFFll) return RWK_E_SIZE;
+    if (rwk_ceil_div(n, 16) + rwk_ceil_div(red_v, 64) * kReduceMaxFinalRows >= 0x7FFFFFFFll) return RWK_E_SIZE;
+    const ReduceJob job{red_in, (long long)red_p, (long long)red_v, red_out32};
+    if (col16 != nullptr)
+        return launch_tile_by_width<int16_t>(crow, col16, val, n, d, x, y, accumulate, (hipStream_t)stream, &job);
+    return launch_tile_by_width<int32_t>(crow, col, val, n, d, x, y, accumulate, (hipStream_t)stream, &job);
 }

@@ -136,13 +136,19 @@ class _RWKernelLayer(torch.autograd.Function):
                                               stream_len, drop, int(normalize), _lib.ptr(rng_used),
                                               dx.data_ptr(), dz_partials.data_ptr(), _lib.ptr(ws), stream),
                        "rwk_fused_backward")
-            for i in range(steps - 1, 0, -1):
-                st.spmm(dx[i], dx[i - 1], transpose=True, accumulate=True)      # dX[i-1] += A^T dX[i]
-            # dZ partials: first level here (to at most 32 rows), the rest inside rwk_hidden_backward
-            dz, dz_rows = dz_partials, n_part
+            # dZ partials: first level here (to at most 32 rows), the rest inside rwk_hidden_backward.  It is
+            # independent of the SpMM chain and rides in the first SpMM's launch when there is one.
+            dz, dz_rows, job = dz_partials, n_part, None
             if n_part > 32:
                 dz_rows = lib.rwk_reduce_rows_level1(n_part)
                 dz = torch.empty((dz_rows, dz_partials.shape[1]), dtype=torch.float32, device=dev)
+                job = (dz_partials, dz)
+            for i in range(steps - 1, 0, -1):                                   # dX[i-1] += A^T dX[i]
+                st.spmm(dx[i], dx[i - 1], transpose=True, accumulate=True,
+                        reduce_job=job if MERGED_LAUNCHES else None)
+                if MERGED_LAUNCHES:
+                    job = None
+            if job is not None:
                 _lib.check(lib.rwk_reduce_rows_to32(dz_partials.data_ptr(), n_part, dz_partials.shape[1],
                                                     dz.data_ptr(), stream), "rwk_reduce_rows_to32")
             d_adj = torch.empty_like(adj_hidden_c)

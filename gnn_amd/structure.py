@@ -211,26 +211,42 @@ class GraphStructure:
 
     # ------------------------------------------------------------------------------------
     def spmm(self, x: torch.Tensor, y: torch.Tensor, transpose: bool = False, accumulate: bool = False,
-             kernel: Optional[str] = None):
+             kernel: Optional[str] = None, reduce_job=None):
         """y = A x (or A^T x), optionally accumulated into y.  x, y: contiguous (N, D) float32.
         ``kernel``: "tile", "tile32" (tile kernel on the int32 columns and the value array) or "packed" to force
-        a schedule (tests); default: the degree-histogram rule, compact structure when it exists."""
+        a schedule (tests); default: the degree-histogram rule, compact structure when it exists.
+        ``reduce_job`` = (partials (P, V), out32 (32, V)), P > 32: also run the first level of the deterministic
+        row reduction of ``partials`` (``rwk_reduce_rows_to32``), in the SpMM's own launch when the tile kernel
+        serves the product."""
         lib = _lib.load()
         csr = self.csr_t if transpose else self.csr
+        stream = _lib.current_stream(self.device)
         tile = use_tile_kernel(self.n, self.nnz, csr.max_degree, x.shape[1]) if kernel is None \
             else kernel in ("tile", "tile32")
-        if tile and csr.col16 is not None and kernel != "tile32":
+        compact = tile and csr.col16 is not None and kernel != "tile32"
+        if tile and reduce_job is not None:
+            red_in, red_out = reduce_job
+            _lib.check(lib.rwk_spmm_tile_reduce_rows(
+                csr.crow.data_ptr(), _lib.ptr(csr.col), csr.col16.data_ptr() if compact else None,
+                None if (compact and csr.unit_values) else _lib.ptr(csr.val), self.n, x.shape[1], x.data_ptr(),
+                y.data_ptr(), int(accumulate), red_in.data_ptr(), red_in.shape[0], red_in.shape[1],
+                red_out.data_ptr(), stream), "rwk_spmm_tile_reduce_rows")
+            return
+        if compact:
             _lib.check(lib.rwk_spmm_csr_compact(csr.crow.data_ptr(), csr.col16.data_ptr(),
                                                 None if csr.unit_values else csr.val.data_ptr(), self.n, x.shape[1],
-                                                x.data_ptr(), y.data_ptr(), int(accumulate),
-                                                _lib.current_stream(self.device)), "rwk_spmm_csr_compact")
-            return
-        n_long = 0 if (tile or csr.long_rows is None) else csr.long_rows.numel()
-        _lib.check(lib.rwk_spmm_csr(csr.crow.data_ptr(), _lib.ptr(csr.col), _lib.ptr(csr.val), self.n,
-                                    x.shape[1], x.data_ptr(), y.data_ptr(), int(accumulate),
-                                    0 if tile else csr.row_lanes,
-                                    _lib.ptr(csr.long_rows), n_long, csr.long_threshold,
-                                    _lib.current_stream(self.device)), "rwk_spmm_csr")
+                                                x.data_ptr(), y.data_ptr(), int(accumulate), stream),
+                       "rwk_spmm_csr_compact")
+        else:
+            n_long = 0 if (tile or csr.long_rows is None) else csr.long_rows.numel()
+            _lib.check(lib.rwk_spmm_csr(csr.crow.data_ptr(), _lib.ptr(csr.col), _lib.ptr(csr.val), self.n,
+                                        x.shape[1], x.data_ptr(), y.data_ptr(), int(accumulate),
+                                        0 if tile else csr.row_lanes,
+                                        _lib.ptr(csr.long_rows), n_long, csr.long_threshold, stream), "rwk_spmm_csr")
+        if reduce_job is not None:
+            red_in, red_out = reduce_job
+            _lib.check(lib.rwk_reduce_rows_to32(red_in.data_ptr(), red_in.shape[0], red_in.shape[1],
+                                                red_out.data_ptr(), stream), "rwk_reduce_rows_to32")
 
     def spmm_bytes(self, d: int) -> int:
         """Algorithmic HBM bytes of one SpMM launch: values + columns + row pointers + x + y."""

@@ -126,6 +126,15 @@ int rwk_csr_compact(const int32_t *crow, const int32_t *col, const float *val, i
 int rwk_spmm_csr_compact(const int32_t *crow, const int16_t *col16, const float *val, int64_t n, int64_t d,
                          const float *x, float *y, int accumulate, rwk_stream_t stream);
 
+/* The tile SpMM (on int32 columns `col`, or on 16-bit distances `col16` when that is not NULL; val == NULL:
+ * all values 1.0f) and the first level of an independent row reduction (red_in (red_p, red_v), red_p > 32,
+ * -> red_out32 (32, red_v), exactly rwk_reduce_rows_to32) in ONE launch.  The backward pass has such a pair:
+ * dx[i-1] += A^T dx[i] and the reduction of the dZ partials, both fed by rwk_fused_backward. */
+int rwk_spmm_tile_reduce_rows(const int32_t *crow, const int32_t *col, const int16_t *col16, const float *val,
+                              int64_t n, int64_t d, const float *x, float *y, int accumulate,
+                              const float *red_in, int64_t red_p, int64_t red_v, float *red_out32,
+                              rwk_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * (2) hidden graphs   Ah = sym(triu(relu(adj_hidden))),  Z[i] = Ah Z[i-1]
  *     replaces model.py:39-42 and :56 for all steps in one launch.

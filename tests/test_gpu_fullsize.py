@@ -129,3 +129,27 @@ def test_graph_permutation_invariance_full_size(dev):
     k2 = m.rw_features(adj2, feats2, gi2).detach().cpu().numpy()
     want = k[order[:64]]
     assert np.abs(k2 - want).max() <= TOL * np.abs(want).max()
+
+
+@pytest.mark.parametrize("name", ["proteins1024", "powerlaw"])
+def test_merged_launches_equal_separate_launches_full_size(name, dev):
+    """At full size the backward pass has more than 32 dZ partial rows, so their first reduction level rides in
+    the SpMM's launch (and the hidden-graph kernels in the projection's): same bits as the stand-alone launches."""
+    import gnn_amd.function as fn
+    hp, b, m = build(name, dev)
+    adj, feats, gi, _ = b.to_torch(dev)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    dk = torch.randn(b.n_graphs, hp["max_step"] * hp["hidden_graphs"], generator=g).to(dev)
+    runs = []
+    try:
+        for merged in (True, False):
+            fn.MERGED_LAUNCHES = merged
+            m.zero_grad(set_to_none=True)
+            k = m.rw_features(adj, feats, gi)
+            k.backward(dk)
+            runs.append([k.detach().clone()] + [p.grad.clone() for p in (m.adj_hidden, m.features_hidden, m.fc.weight,
+                                                                      m.fc.bias)])
+    finally:
+        fn.MERGED_LAUNCHES = True
+    for a, c in zip(*runs):
+        assert torch.equal(a, c)
