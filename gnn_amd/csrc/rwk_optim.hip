@@ -9,6 +9,18 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// b^t for an integer step count by repeated squaring: a few dozen double multiplications instead of the
+// log/exp evaluation behind pow() (one thread computes it while its workgroup waits)
+__device__ inline double pow_int(double b, long long t) {
+    double r = 1.0;
+    while (t > 0) {
+        if (t & 1) r *= b;
+        b *= b;
+        t >>= 1;
+    }
+    return r;
+}
+
 __global__ void __launch_bounds__(kBlock)
 adam_step_kernel(float *__restrict__ param, const float *__restrict__ grad, float *__restrict__ exp_avg,
                  float *__restrict__ exp_avg_sq, long long n, const float *__restrict__ lr_ptr, float beta1,
@@ -17,8 +29,8 @@ adam_step_kernel(float *__restrict__ param, const float *__restrict__ grad, floa
     if (threadIdx.x == 0) {
         const long long t = step_counters[blockIdx.x] + 1;
         step_counters[blockIdx.x] = t;
-        corr[0] = (float)(1.0 - pow((double)beta1, (double)t));
-        corr[1] = (float)sqrt(1.0 - pow((double)beta2, (double)t));
+        corr[0] = (float)(1.0 - pow_int((double)beta1, t));
+        corr[1] = (float)sqrt(1.0 - pow_int((double)beta2, t));
     }
     __syncthreads();
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
@@ -53,8 +65,8 @@ adam_step_chunks_kernel(float *__restrict__ param, AdamChunks a, float *__restri
     if (threadIdx.x == 0) {
         const long long t = step_counters[blockIdx.x] + 1;
         step_counters[blockIdx.x] = t;
-        corr[0] = (float)(1.0 - pow((double)beta1, (double)t));
-        corr[1] = (float)sqrt(1.0 - pow((double)beta2, (double)t));
+        corr[0] = (float)(1.0 - pow_int((double)beta1, t));
+        corr[1] = (float)sqrt(1.0 - pow_int((double)beta2, t));
     }
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     const long long ic = i < n ? i : n - 1;
