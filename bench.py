@@ -51,7 +51,7 @@ def parse_args():
                     help="flat: gnn_amd.optim.FlatAdam (one launch); torch: torch.optim.Adam(capturable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--cpu-sample-graphs", type=int, default=128)
+    ap.add_argument("--cpu-sample-graphs", type=int, default=1024)
     ap.add_argument("--kernels-only", action="store_true",
                     help="no training loop: time the hand-written kernels on the (tiled) batch and print them")
     ap.add_argument("--roofline-scale", type=int, default=1,
