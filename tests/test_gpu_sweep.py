@@ -1,0 +1,91 @@
+"""Hyper-parameter sweep of the random-walk-kernel layer against the float64 oracle: every kernel family (vector
+ALU for hidden_dim <= 4, fp32 matrix cores for 8..64, generic) over hidden-graph counts, sizes, widths and step
+counts that the golden cases do not reach, without dropout and with the oracle's restatement of the dropout mask.
+The graphs are a small random batch (sorted indicator, symmetric unweighted adjacency, a few isolated nodes)."""
+import numpy as np
+import pytest
+import torch
+
+from _golden import rel_err
+from oracle import rwnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+#        H   S   D  L  normalize
+SWEEP = [(16, 3, 4, 1, False), (16, 4, 3, 2, True), (7, 5, 4, 3, False), (16, 6, 2, 4, True), (12, 8, 4, 2, False),
+         (16, 10, 4, 3, True), (33, 5, 4, 2, False), (64, 6, 1, 2, False), (3, 3, 4, 4, True), (16, 5, 4, 4, False),
+         (16, 5, 8, 2, False), (20, 3, 16, 3, True), (48, 10, 32, 2, False), (64, 12, 64, 1, True),
+         (9, 7, 12, 2, False), (16, 5, 20, 4, True), (5, 2, 8, 3, False), (16, 11, 4, 2, False), (2, 9, 5, 2, True),
+         (40, 4, 24, 2, False)]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def batch():
+    rng = np.random.default_rng(2024)
+    sizes = rng.integers(1, 40, size=57)
+    sizes[5] = 1                                           # a single-node graph
+    n = int(sizes.sum())
+    gi = np.repeat(np.arange(sizes.size), sizes)
+    rows, cols = [], []
+    start = 0
+    for m in sizes:
+        if m > 1:
+            e = rng.integers(0, m, size=(max(1, int(1.3 * m)), 2))
+            e = e[e[:, 0] != e[:, 1]]
+            rows += [start + e[:, 0], start + e[:, 1]]
+            cols += [start + e[:, 1], start + e[:, 0]]
+        start += m
+    r, c = np.concatenate(rows), np.concatenate(cols)
+    key = np.unique(r.astype(np.int64) * n + c)
+    idx = np.vstack([key // n, key % n])
+    val = np.ones(idx.shape[1], dtype=np.float32)
+    return n, gi.astype(np.int64), idx, val
+
+
+@pytest.mark.parametrize("h,s,d,steps,normalize", SWEEP)
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_layer_sweep(h, s, d, steps, normalize, p, batch, dev):
+    from gnn_amd import _lib, get_structure, rw_kernel_layer
+    n, gi, idx, val = batch
+    rng = np.random.default_rng(h * 1000 + s * 100 + d * 10 + steps)
+    pre = rng.normal(size=(n, d)).astype(np.float32)
+    adj_h = rng.uniform(-1, 1, size=(h, s * (s - 1) // 2)).astype(np.float32)
+    z0 = rng.uniform(0, 1, size=(h, s, d)).astype(np.float32)
+    g = int(gi.max()) + 1
+    dk = rng.normal(size=(g, steps * h)).astype(np.float32)
+
+    adj = torch.sparse_coo_tensor(torch.from_numpy(idx), torch.from_numpy(val), (n, n)).to(dev)
+    st = get_structure(adj, torch.from_numpy(gi).to(dev))
+    pre_t = torch.from_numpy(pre).to(dev).requires_grad_(True)
+    adj_t = torch.from_numpy(adj_h).to(dev).requires_grad_(True)
+    z_t = torch.from_numpy(z0).to(dev).requires_grad_(True)
+    seed, offset = 0xC0FFEE123, 9
+    rng_state = torch.tensor([seed, offset], dtype=torch.int64, device=dev) if p else None
+    k = rw_kernel_layer(pre_t, adj_t, z_t, st, steps, normalize, p, rng_state)
+    k.backward(torch.from_numpy(dk).to(dev))
+
+    keep = O.dropout_keep(seed, offset, n, h, s, steps, p) if p else None
+    if p:                                                  # the kernel's own mask is the oracle's, bit for bit
+        keep_dev = torch.empty((steps, h, s, n), dtype=torch.uint8, device=dev)
+        rs = torch.tensor([seed, offset], dtype=torch.int64, device=dev)
+        _lib.check(_lib.load().rwk_dropout_mask(rs.data_ptr(), n, h, s, steps, p, keep_dev.data_ptr(),
+                                                _lib.current_stream(dev)), "rwk_dropout_mask")
+        assert np.array_equal(keep_dev.cpu().numpy().astype(bool), keep)
+    csr = O.coo_to_csr(idx, val, n)
+    x0 = 1.0 / (1.0 + np.exp(-pre.astype(np.float64)))
+    kw = dict(keep=keep, drop_p=p) if p else {}
+    k_ref = O.rw_kernel_forward(csr, x0, adj_h, z0, gi, steps, normalize, **kw)
+    d_x0, d_adj, d_feat = O.rw_kernel_backward(csr, x0, adj_h, z0, gi, steps, dk, normalize, **kw)
+    assert rel_err(k.detach().cpu().numpy(), k_ref) < TOL
+    assert rel_err(z_t.grad.cpu().numpy(), d_feat) < TOL
+    assert rel_err(pre_t.grad.cpu().numpy(), d_x0 * x0 * (1 - x0)) < TOL
+    if steps > 1 and s > 1:
+        assert rel_err(adj_t.grad.cpu().numpy(), d_adj) < TOL
