@@ -1,0 +1,92 @@
+"""Row-normalised random-walk propagation layer ``RWConv`` (``rwgnn/rwgnn_pyg.py:19-46``) on the SpMM engine.
+
+The reference builds it on torch_geometric's ``MessagePassing`` (``aggr='add'``): self-loops are appended to
+``edge_index`` for every node (``add_self_loops``, existing ones stay), ``deg`` counts how often a node is the
+SOURCE of an edge (``degree(row)``, ``:30-31``), every edge ``j -> i`` carries ``x[j] / deg[j]`` (``:34,42``),
+messages are summed at the target, and a ``Linear`` follows (``:46``).  In matrix form ``out = lin(M x)`` with
+``M[i, j] = (number of edges j -> i, self-loop included) / deg[j]``.  Here ``M`` is built once per ``edge_index``
+tensor (cached by identity) as a CSR with those values, and ``M x`` / ``M^T dy`` are launches of the same SpMM
+kernels the random-walk-kernel layer uses.  Only the propagation operator of that model family is covered; its
+per-hidden-node output layout (``:128-150``) is not.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .structure import GraphStructure
+
+__all__ = ["RWConv", "propagation_structure", "propagate"]
+
+_CACHE: "OrderedDict[tuple, GraphStructure]" = OrderedDict()
+_CACHE_CAPACITY = 256
+
+
+def propagation_structure(edge_index: torch.Tensor, num_nodes: int) -> GraphStructure:
+    """CSR of ``M`` (and of ``M^T``) for ``edge_index`` (2, E) int64 on a HIP device; cached by tensor identity."""
+    if edge_index.dim() != 2 or edge_index.shape[0] != 2 or edge_index.dtype != torch.int64:
+        raise TypeError("edge_index must be an int64 tensor of shape (2, E)")
+    if not edge_index.is_cuda:
+        raise RuntimeError("gnn_amd runs on HIP devices only (no CPU fallback)")
+    key = (edge_index.data_ptr(), edge_index.shape[1], edge_index._version, int(num_nodes), str(edge_index.device))
+    st = _CACHE.get(key)
+    if st is not None:
+        _CACHE.move_to_end(key)
+        return st
+    dev = edge_index.device
+    loops = torch.arange(num_nodes, dtype=torch.int64, device=dev)
+    src = torch.cat([edge_index[0], loops])                      # add_self_loops, rwgnn_pyg.py:27
+    dst = torch.cat([edge_index[1], loops])
+    deg = torch.bincount(src, minlength=num_nodes).to(torch.float32)        # degree(row), :31
+    deg_inv = torch.where(deg > 0, 1.0 / deg, torch.zeros_like(deg))        # :32-33
+    # row = target, column = source; duplicates of an edge add up, as the scatter-add of aggr='add' does
+    m = torch.sparse_coo_tensor(torch.stack([dst, src]), deg_inv[src], (num_nodes, num_nodes)).coalesce()
+    st = GraphStructure.build(m, torch.zeros(num_nodes, dtype=torch.int64, device=dev))
+    st._keepalive = (edge_index,)
+    _CACHE[key] = st
+    while len(_CACHE) > _CACHE_CAPACITY:
+        _CACHE.popitem(last=False)
+    return st
+
+
+class _Propagate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, st: GraphStructure):
+        if not x.is_cuda:
+            raise RuntimeError("gnn_amd runs on HIP devices only (no CPU fallback)")
+        if x.dim() != 2 or x.shape[0] != st.n:
+            raise ValueError(f"x has shape {tuple(x.shape)} for {st.n} nodes")
+        if x.shape[1] > 64:
+            raise NotImplementedError("the SpMM kernels cover up to 64 channels")
+        xc = x.detach().contiguous().float()
+        y = torch.empty_like(xc)
+        st.spmm(xc, y)
+        ctx.st = st
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        dyc = dy.contiguous().float()
+        dx = torch.empty_like(dyc)
+        ctx.st.spmm(dyc, dx, transpose=True)
+        return dx, None
+
+
+def propagate(x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
+    """``M x``: every node receives ``x[j] / deg[j]`` from each of its in-edges ``j -> i`` and from itself."""
+    return _Propagate.apply(x, propagation_structure(edge_index, x.shape[0]))
+
+
+class RWConv(nn.Module):
+    """Same constructor, parameters (``lin.weight``, ``lin.bias``) and ``forward(x, edge_index)`` as the
+    reference's ``RWConv``."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.lin = nn.Linear(in_channels, out_channels)
+
+    def forward(self, x, edge_index):
+        return self.lin(propagate(x, edge_index))

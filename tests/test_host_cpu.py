@@ -3,6 +3,7 @@ reference's interface, and the product path refuses to run without a HIP device 
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 
@@ -116,3 +117,26 @@ def test_stream_length_rule():
     assert choose_stream_len(103008, 64, 64, 10, 2) == 13
     assert choose_stream_len(103008, 64, 64, 10, 2, backward=True) == 13
     assert choose_stream_len(0, 4, 16, 5, 2) == 0
+
+def test_rwconv_oracle_against_dense_matrix():
+    """oracle/rwconv_oracle.py (edge-list form) against the dense matrix M[i, j] = #edges(j -> i) / deg[j] it
+    restates, forward and VJP, on a graph with duplicate edges, self-loops and an isolated node."""
+    from oracle import rwconv_oracle as R
+    rng = np.random.default_rng(0)
+    n = 12
+    ei = np.vstack([rng.integers(0, n - 1, 30), rng.integers(0, n - 1, 30)])
+    ei = np.concatenate([ei, ei[:, :4], np.array([[2, 2], [2, 2]])], axis=1)
+    x, w, b = rng.normal(size=(n, 3)), rng.normal(size=(2, 3)), rng.normal(size=2)
+    d = rng.normal(size=(n, 2))
+    src = np.concatenate([ei[0], np.arange(n)])
+    dst = np.concatenate([ei[1], np.arange(n)])
+    deg = np.bincount(src, minlength=n)
+    m = np.zeros((n, n))
+    for s_, t_ in zip(src, dst):
+        m[t_, s_] += 1.0 / deg[s_]
+    out, agg = R.rwconv_forward(x, ei, w, b)
+    assert np.abs(out - (m @ x @ w.T + b)).max() < 1e-12 and np.abs(agg - m @ x).max() < 1e-12
+    assert np.abs(m.sum(0) - 1.0).max() < 1e-12          # every node hands out exactly its own value
+    dx, dw, db = R.rwconv_backward(x, ei, w, d)
+    assert np.abs(dx - m.T @ (d @ w)).max() < 1e-12
+    assert np.abs(dw - d.T @ (m @ x)).max() < 1e-12 and np.abs(db - d.sum(0)).max() < 1e-12
