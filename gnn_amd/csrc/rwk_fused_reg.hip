@@ -456,6 +456,7 @@ int launch_bwd(const Args &a) {
 template <int LT>
 int by_s(const Args &a, bool bwd) {
     switch (a.s) {
+        case 1: return bwd ? launch_bwd<LT, 1>(a) : launch_fwd<LT, 1>(a);
         case 3: return bwd ? launch_bwd<LT, 3>(a) : launch_fwd<LT, 3>(a);
         case 4: return bwd ? launch_bwd<LT, 4>(a) : launch_fwd<LT, 4>(a);
         case 5: return bwd ? launch_bwd<LT, 5>(a) : launch_fwd<LT, 5>(a);
@@ -480,7 +481,7 @@ int by_l(const Args &a, bool bwd) {
 
 bool supported(int64_t d, int64_t h, int64_t s, int64_t max_step) {
     if (d < 1 || d > DP || h < 1 || h > 64 || max_step < 1 || max_step > 4) return false;
-    return s == 3 || s == 4 || s == 5 || s == 6 || s == 8 || s == 10;
+    return s == 1 || s == 3 || s == 4 || s == 5 || s == 6 || s == 8 || s == 10;
 }
 
 int64_t backward_blocks(int64_t n, int64_t stream_len, int64_t h) {

@@ -24,13 +24,15 @@ _CACHE: "OrderedDict[tuple, GraphStructure]" = OrderedDict()
 _CACHE_CAPACITY = 256
 
 
-def propagation_structure(edge_index: torch.Tensor, num_nodes: int) -> GraphStructure:
-    """CSR of ``M`` (and of ``M^T``) for ``edge_index`` (2, E) int64 on a HIP device; cached by tensor identity."""
+def propagation_structure(edge_index: torch.Tensor, num_nodes: int, batch: torch.Tensor = None) -> GraphStructure:
+    """CSR of ``M`` (and of ``M^T``) for ``edge_index`` (2, E) int64 on a HIP device; cached by tensor identity.
+    ``batch`` (N,) int64: the graph of every node, for callers that also need the per-graph segments."""
     if edge_index.dim() != 2 or edge_index.shape[0] != 2 or edge_index.dtype != torch.int64:
         raise TypeError("edge_index must be an int64 tensor of shape (2, E)")
     if not edge_index.is_cuda:
         raise RuntimeError("gnn_amd runs on HIP devices only (no CPU fallback)")
-    key = (edge_index.data_ptr(), edge_index.shape[1], edge_index._version, int(num_nodes), str(edge_index.device))
+    key = (edge_index.data_ptr(), edge_index.shape[1], edge_index._version, int(num_nodes), str(edge_index.device),
+           None if batch is None else (batch.data_ptr(), batch._version))
     st = _CACHE.get(key)
     if st is not None:
         _CACHE.move_to_end(key)
@@ -43,8 +45,8 @@ def propagation_structure(edge_index: torch.Tensor, num_nodes: int) -> GraphStru
     deg_inv = torch.where(deg > 0, 1.0 / deg, torch.zeros_like(deg))        # :32-33
     # row = target, column = source; duplicates of an edge add up, as the scatter-add of aggr='add' does
     m = torch.sparse_coo_tensor(torch.stack([dst, src]), deg_inv[src], (num_nodes, num_nodes)).coalesce()
-    st = GraphStructure.build(m, torch.zeros(num_nodes, dtype=torch.int64, device=dev))
-    st._keepalive = (edge_index,)
+    st = GraphStructure.build(m, batch if batch is not None else torch.zeros(num_nodes, dtype=torch.int64, device=dev))
+    st._keepalive = (edge_index, batch)
     _CACHE[key] = st
     while len(_CACHE) > _CACHE_CAPACITY:
         _CACHE.popitem(last=False)
