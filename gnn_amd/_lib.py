@@ -55,6 +55,8 @@ SIGNATURES = {
     "rwk_project_forward": (c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
     "rwk_project_backward_blocks": (_I64, [_I64, _I64]),
     "rwk_project_backward": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P]),
+    "rwk_linear_forward": (c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
+    "rwk_linear_backward": (c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P]),
     "rwk_project_hidden_forward": (c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P,
                                            _P]),
     "rwk_project_hidden_backward": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64,

@@ -13,6 +13,7 @@ namespace {
 constexpr int kBlock = kProjectBlock;
 
 // one thread per (node, output channel); 32-bit index arithmetic (n * d < 2^31 is checked by the launcher)
+template <bool SIGMOID>
 __global__ void __launch_bounds__(kBlock)
 project_forward_kernel(const float *__restrict__ feat, const float *__restrict__ w, const float *__restrict__ b,
                        int n, int f, int d, float *__restrict__ x0) {
@@ -24,23 +25,23 @@ project_forward_kernel(const float *__restrict__ feat, const float *__restrict__
     const float *fr = feat + (size_t)node * f;
     const float *wr = w + (size_t)c * f;
     for (int k = 0; k < f; ++k) acc = fmaf(fr[k], wr[k], acc);
-    x0[t] = 1.0f / (1.0f + expf(-acc));
+    x0[t] = SIGMOID ? 1.0f / (1.0f + expf(-acc)) : acc;
 }
 
-template <int FP>
+template <int FP, bool SIGMOID>
 __global__ void __launch_bounds__(kBlock)
 project_forward4_kernel(const float *__restrict__ feat, const float *__restrict__ w, const float *__restrict__ b,
                         int n, int f, float *__restrict__ x0) {
-    project_forward4_body<FP>(blockIdx.x, feat, w, b, n, f, x0);
+    project_forward4_body<FP, SIGMOID>(blockIdx.x, feat, w, b, n, f, x0);
 }
 
-template <int FP>
+template <int FP, bool SIGMOID>
 __global__ void __launch_bounds__(kBlock)
 project_backward_kernel(const float *__restrict__ dx0, const float *__restrict__ x0,
                         const float *__restrict__ feat, const float *__restrict__ w, long long n, int f, int d,
                         int dpad, float *__restrict__ partials, float *__restrict__ d_feat) {
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [FP + 1][kBlock]
-    project_backward_body<FP>(blockIdx.x, gridDim.x, lds, dx0, x0, feat, w, n, f, d, dpad, partials, d_feat);
+    project_backward_body<FP, SIGMOID>(blockIdx.x, gridDim.x, lds, dx0, x0, feat, w, n, f, d, dpad, partials, d_feat);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -158,8 +159,11 @@ int rwk_reduce_rows(const float *in, int64_t p, int64_t v, float *out, float *wo
     return RWK_OK;
 }
 
-int rwk_project_forward(const float *features, const float *weight, const float *bias, int64_t n, int64_t f,
-                        int64_t d, float *x0, rwk_stream_t stream) {
+}  // extern "C"
+
+template <bool SIGMOID>
+static int project_forward_impl(const float *features, const float *weight, const float *bias, int64_t n, int64_t f,
+                                int64_t d, float *x0, rwk_stream_t stream) {
     RWK_REQUIRE_PTR(features);
     RWK_REQUIRE_PTR(weight);
     RWK_REQUIRE_PTR(bias);
@@ -168,19 +172,32 @@ int rwk_project_forward(const float *features, const float *weight, const float 
     hipStream_t s = (hipStream_t)stream;
     if (d == 4 && f <= 8 && ((uintptr_t)x0 & 15u) == 0) {
         const dim3 grid((unsigned)rwk_ceil_div(n, kBlock));
-#define RWK_PF(FP) \
-    hipLaunchKernelGGL((project_forward4_kernel<FP>), grid, dim3(kBlock), 0, s, features, weight, bias, (int)n, (int)f, x0)
+#define RWK_PF(FP)                                                                                                \
+    hipLaunchKernelGGL((project_forward4_kernel<FP, SIGMOID>), grid, dim3(kBlock), 0, s, features, weight, bias, (int)n, \
+                       (int)f, x0)
         if (f == 1) RWK_PF(1);
         else if (f == 2) RWK_PF(2);
         else if (f <= 4) RWK_PF(4);
         else RWK_PF(8);
 #undef RWK_PF
     } else {
-        hipLaunchKernelGGL(project_forward_kernel, dim3((unsigned)rwk_ceil_div(n * d, kBlock)), dim3(kBlock), 0, s,
-                           features, weight, bias, (int)n, (int)f, (int)d, x0);
+        hipLaunchKernelGGL((project_forward_kernel<SIGMOID>), dim3((unsigned)rwk_ceil_div(n * d, kBlock)), dim3(kBlock),
+                           0, s, features, weight, bias, (int)n, (int)f, (int)d, x0);
     }
     RWK_LAUNCH_CHECK();
     return RWK_OK;
+}
+
+extern "C" {
+
+int rwk_project_forward(const float *features, const float *weight, const float *bias, int64_t n, int64_t f,
+                        int64_t d, float *x0, rwk_stream_t stream) {
+    return project_forward_impl<true>(features, weight, bias, n, f, d, x0, stream);
+}
+
+int rwk_linear_forward(const float *x, const float *weight, const float *bias, int64_t n, int64_t f, int64_t d,
+                       float *y, rwk_stream_t stream) {
+    return project_forward_impl<false>(x, weight, bias, n, f, d, y, stream);
 }
 
 int64_t rwk_project_backward_blocks(int64_t n, int64_t d) {
@@ -192,9 +209,12 @@ int64_t rwk_project_backward_blocks(int64_t n, int64_t d) {
     return blocks;
 }
 
-int rwk_project_backward(const float *dx0, const float *x0, const float *features, const float *weight,
-                         int64_t n, int64_t f, int64_t d, float *partials, float *d_features,
-                         rwk_stream_t stream) {
+}  // extern "C"
+
+template <bool SIGMOID>
+static int project_backward_impl(const float *dx0, const float *x0, const float *features, const float *weight,
+                                 int64_t n, int64_t f, int64_t d, float *partials, float *d_features,
+                                 rwk_stream_t stream) {
     RWK_REQUIRE_PTR(dx0);
     RWK_REQUIRE_PTR(x0);
     RWK_REQUIRE_PTR(features);
@@ -206,8 +226,9 @@ int rwk_project_backward(const float *dx0, const float *x0, const float *feature
     const unsigned blocks = (unsigned)rwk_project_backward_blocks(n, d);
     hipStream_t s = (hipStream_t)stream;
 #define RWK_PB(FP)                                                                                              \
-    hipLaunchKernelGGL((project_backward_kernel<FP>), dim3(blocks), dim3(kBlock), (FP + 1) * kBlock * sizeof(float), s, \
-                       dx0, x0, features, weight, (long long)n, (int)f, (int)d, dpad, partials, d_features)
+    hipLaunchKernelGGL((project_backward_kernel<FP, SIGMOID>), dim3(blocks), dim3(kBlock),                      \
+                       (FP + 1) * kBlock * sizeof(float), s, dx0, x0, features, weight, (long long)n, (int)f,   \
+                       (int)d, dpad, partials, d_features)
     if (f == 1) RWK_PB(1);
     else if (f == 2) RWK_PB(2);
     else if (f <= 4) RWK_PB(4);
@@ -215,6 +236,20 @@ int rwk_project_backward(const float *dx0, const float *x0, const float *feature
 #undef RWK_PB
     RWK_LAUNCH_CHECK();
     return RWK_OK;
+}
+
+extern "C" {
+
+int rwk_project_backward(const float *dx0, const float *x0, const float *features, const float *weight,
+                         int64_t n, int64_t f, int64_t d, float *partials, float *d_features,
+                         rwk_stream_t stream) {
+    return project_backward_impl<true>(dx0, x0, features, weight, n, f, d, partials, d_features, stream);
+}
+
+int rwk_linear_backward(const float *d_y, const float *x, const float *weight, int64_t n, int64_t f, int64_t d,
+                        float *partials, float *d_x, rwk_stream_t stream) {
+    // the body reads its second argument only for the activation's derivative: any valid (n, d) buffer will do
+    return project_backward_impl<false>(d_y, d_y, x, weight, n, f, d, partials, d_x, stream);
 }
 
 }  // extern "C"

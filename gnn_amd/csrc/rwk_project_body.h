@@ -13,7 +13,8 @@ static inline int project_pow2_ceil(int x) {
 }
 
 // hidden_dim 4 (the reference's default): one thread per node, one 16-byte store per row
-template <int FP>
+// SIGMOID = false: the same bodies without the activation (a plain Linear with narrow input)
+template <int FP, bool SIGMOID = true>
 __device__ inline void project_forward4_body(int block, const float *__restrict__ feat, const float *__restrict__ w,
                                              const float *__restrict__ b, int n, int f, float *__restrict__ x0) {
     const int node = block * kProjectBlock + threadIdx.x;
@@ -28,7 +29,7 @@ __device__ inline void project_forward4_body(int block, const float *__restrict_
 #pragma unroll
         for (int k = 0; k < FP; ++k)
             if (k < f) acc = fmaf(fr[k], w[c * f + k], acc);
-        o[c] = 1.0f / (1.0f + expf(-acc));
+        o[c] = SIGMOID ? 1.0f / (1.0f + expf(-acc)) : acc;
     }
     reinterpret_cast<float4 *>(x0)[node] = make_float4(o[0], o[1], o[2], o[3]);
 }
@@ -36,7 +37,7 @@ __device__ inline void project_forward4_body(int block, const float *__restrict_
 // Thread (slot, c): c = output channel, slot strides over nodes.  FP = padded input width.
 // partials row layout: [c * f + k] for dW (d*f values) then [d*f + c] for db.
 // workgroup `block` of `grid`; lds: (FP + 1) * kProjectBlock floats
-template <int FP>
+template <int FP, bool SIGMOID = true>
 __device__ inline void project_backward_body(int block, int grid, float *lds, const float *__restrict__ dx0,
                                              const float *__restrict__ x0, const float *__restrict__ feat,
                                              const float *__restrict__ w, long long n, int f, int d, int dpad,
@@ -75,7 +76,7 @@ __device__ inline void project_backward_body(int block, int grid, float *lds, co
             if (r0 + u >= rounds) break;                  // uniform
             const long long node = (r0 + u) * per_round + (long long)block * slots + slot;
             const bool valid = node < n && own;
-            const float dpre = valid ? dv[u] * xv[u] * (1.0f - xv[u]) : 0.f;
+            const float dpre = valid ? (SIGMOID ? dv[u] * xv[u] * (1.0f - xv[u]) : dv[u]) : 0.f;
             acc_b += dpre;
 #pragma unroll
             for (int k = 0; k < FP; ++k) acc_w[k] = fmaf(dpre, (valid && k < f) ? fr[u][k] : 0.f, acc_w[k]);

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .function import _reduce_rows, choose_stream_len
-from .rwconv import RWConv, propagation_structure
+from .rwconv import RWConv, narrow_linear, propagation_structure
 from .structure import GraphStructure
 
 __all__ = ["RW_GNN", "hidden_chain", "pair_kernel_features"]
@@ -218,7 +218,7 @@ class RW_GNN(nn.Module):
         x, edge_index, batch = data.x, data.edge_index, data.batch
         st = propagation_structure(edge_index, x.shape[0], batch)
         g, h, s = st.n_graphs, self.hidden_graphs, self.size_hidden_graphs
-        x = self.sigmoid(self.fc(x))                                          # :113
+        x = self.sigmoid(narrow_linear(x, self.fc.weight, self.fc.bias))     # :113
         steps = [x]
         for i in range(1, self.max_step):
             steps.append(self.rw_layers[i - 1](steps[-1], edge_index))        # :128

@@ -16,9 +16,11 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
+from . import _lib
+from .function import _reduce_rows
 from .structure import GraphStructure
 
-__all__ = ["RWConv", "propagation_structure", "propagate"]
+__all__ = ["RWConv", "propagation_structure", "propagate", "narrow_linear"]
 
 _CACHE: "OrderedDict[tuple, GraphStructure]" = OrderedDict()
 _CACHE_CAPACITY = 256
@@ -82,6 +84,53 @@ def propagate(x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
     return _Propagate.apply(x, propagation_structure(edge_index, x.shape[0]))
 
 
+class _NarrowLinear(torch.autograd.Function):
+    """``x W^T + b`` for at most 8 input and 64 output channels (``rwgnn_pyg.py:46`` at the reference's widths):
+    the narrow-input kernels of the input projection without their sigmoid, instead of a GEMM library's
+    N x 4 times 4 x 4 product and its N-long weight-gradient reduction."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        dev = x.device
+        n, f = x.shape
+        d = weight.shape[0]
+        xc, wc = x.detach().contiguous().float(), weight.detach().contiguous().float()
+        y = torch.empty((n, d), dtype=torch.float32, device=dev)
+        with _lib.device_guard(dev):
+            _lib.check(lib.rwk_linear_forward(xc.data_ptr(), wc.data_ptr(), bias.detach().contiguous().float().data_ptr(),
+                                              n, f, d, y.data_ptr(), _lib.current_stream(dev)), "rwk_linear_forward")
+        ctx.save_for_backward(xc, wc)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_y):
+        lib = _lib.load()
+        xc, wc = ctx.saved_tensors
+        dev = xc.device
+        n, f = xc.shape
+        d = wc.shape[0]
+        d_yc = d_y.contiguous().float()
+        blocks = lib.rwk_project_backward_blocks(n, d)
+        partials = torch.empty((blocks, d * f + d), dtype=torch.float32, device=dev)
+        d_x = torch.empty_like(xc) if ctx.needs_input_grad[0] else None
+        with _lib.device_guard(dev):
+            stream = _lib.current_stream(dev)
+            _lib.check(lib.rwk_linear_backward(d_yc.data_ptr(), xc.data_ptr(), wc.data_ptr(), n, f, d,
+                                               partials.data_ptr(), _lib.ptr(d_x), stream), "rwk_linear_backward")
+            wb = _reduce_rows(lib, partials, stream)
+        return d_x, wb[:d * f].view(d, f), wb[d * f:]
+
+
+def narrow_linear(x, weight, bias):
+    """``F.linear(x, weight, bias)`` on the narrow-input kernels when they cover the widths, else torch's."""
+    if x.is_cuda and x.dim() == 2 and bias is not None and x.shape[1] <= 8 and weight.shape[0] <= 64 \
+            and x.shape[0] > 0:
+        return _NarrowLinear.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)
+
+
 class RWConv(nn.Module):
     """Same constructor, parameters (``lin.weight``, ``lin.bias``) and ``forward(x, edge_index)`` as the
     reference's ``RWConv``."""
@@ -91,4 +140,4 @@ class RWConv(nn.Module):
         self.lin = nn.Linear(in_channels, out_channels)
 
     def forward(self, x, edge_index):
-        return self.lin(propagate(x, edge_index))
+        return narrow_linear(propagate(x, edge_index), self.lin.weight, self.lin.bias)

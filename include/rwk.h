@@ -276,6 +276,16 @@ int rwk_project_backward(const float *dx0, const float *x0, const float *feature
                          const float *weight, int64_t n, int64_t f, int64_t d, float *partials,
                          float *d_features, rwk_stream_t stream);
 
+/* The same two kernels without the sigmoid: y = x W^T + b for narrow inputs (f <= 8 input, d <= 64 output
+ * channels), the Linear inside RWConv (rwgnn/rwgnn_pyg.py:23,46) at hidden_dim 4, which a GEMM library serves
+ * badly (N x 4 times 4 x 4, and an N-long reduction for the weight gradient).  Backward: per-workgroup partial
+ * rows [dW (d, f) | db (d)] (rwk_project_backward_blocks(n, d) of them, add with rwk_reduce_rows) and d_x (n, f),
+ * which may be NULL. */
+int rwk_linear_forward(const float *x, const float *weight, const float *bias, int64_t n, int64_t f, int64_t d,
+                       float *y, rwk_stream_t stream);
+int rwk_linear_backward(const float *d_y, const float *x, const float *weight, int64_t n, int64_t f, int64_t d,
+                        float *partials, float *d_x, rwk_stream_t stream);
+
 /* rwk_hidden_forward and rwk_project_forward in ONE launch (model.py:39-43,56: neither depends on the other),
  * for hidden_dim d = 4 and f <= 8 input features (RWK_E_UNSUPPORTED otherwise: launch the two separately).
  * Arguments and results as the two stand-alone entry points. */
