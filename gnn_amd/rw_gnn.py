@@ -3,7 +3,8 @@ a ``Linear`` per step, and random-walk-kernel features kept per hidden NODE (G x
 
 Kept per hidden node, the feature of (hidden graph h, hidden node s) is what the fused kernels compute for a
 hidden graph of size one whose only row is ``Z_i[h, s]``: the H*S pairs are therefore handed to the same kernels as
-H*S one-node hidden graphs, sixteen (hidden_dim <= 4) or up to sixty-four at a launch.  The hidden-graph chain
+H*S one-node hidden graphs, up to sixty-four at a launch (fewer, larger launches beat the sixteen-lane kernel
+instances here: the step is bound by the host's launch rate).  The hidden-graph chain
 ``Z_i = Ah Z_{i-1}`` and its backward are the usual kernels on the real H x S graphs; the node features of the steps
 (``x_i = lin_i(M x_{i-1})``) are built by autograd from :mod:`gnn_amd.rwconv` and enter the fused kernels as a
 stack, whose gradient they return.
@@ -72,7 +73,8 @@ def hidden_chain(adj_hidden, features_hidden, steps: int):
 
 
 def _chunk(d: int) -> int:
-    return 16 if d <= 4 else 64
+    """Pairs per launch: the kernels' limit on hidden graphs."""
+    return 64
 
 
 class _PairKernels(torch.autograd.Function):
