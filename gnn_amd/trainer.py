@@ -31,9 +31,14 @@ class Trainer:
     """
 
     def __init__(self, model, batch_t, world: int = 1, optimizer: str = "flat", lr: float = 1e-2,
-                 fused_loss: bool = True, capture_error_mode: str = None, sync_before_all_reduce: bool = False):
+                 fused_loss: bool = True, capture_error_mode: str = None, sync_before_all_reduce: bool = False,
+                 forward_fn=None):
         self.model = model
         self.adj, self.feats, self.gi, self.y = batch_t
+        # forward_fn(): the model's scores for the resident batch, for models with another call signature than
+        # RW_NN's (gnn_amd.rw_gnn.RW_GNN takes one ``data`` object); its lazily created layers must exist already
+        self.forward_fn = forward_fn if forward_fn is not None else (
+            lambda: self.model(self.adj, self.feats, self.gi))
         self.bucket = FlatGradBucket(model)
         self.world = world
         if optimizer == "flat":       # main.py:79: Adam, lr 1e-2
@@ -52,13 +57,13 @@ class Trainer:
         self.capture_error_mode = capture_error_mode or ("thread_local" if world > 1 else "global")
         self.loss = None
         # d(loss)/d(loss) = 1, kept resident: backward() would otherwise launch a fill for it every step
-        self._one = torch.ones((), dtype=torch.float32, device=self.feats.device)
+        self._one = torch.ones((), dtype=torch.float32, device=self.y.device)
         self.g_fb = None
         self.g_opt = None
 
     def fwd_bwd(self):
         self.bucket.release()            # optimizer.zero_grad(set_to_none=True)
-        out = self.model(self.adj, self.feats, self.gi)
+        out = self.forward_fn()
         self.loss = self.loss_fn(out, self.y)
         self.loss.backward(self._one)
         if not self.fused_gather:

@@ -29,6 +29,16 @@ for _ in range(50): step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 50
 print('RW_GNN train step: %.3f ms, %.2f M graphs/s (1024 graphs, %d nodes)' % (dt * 1e3, 1024 / dt / 1e6, b.n_nodes))
+from gnn_amd.trainer import Trainer
+tr = Trainer(m, (adj, feats, gi, y), 1, forward_fn=lambda: m(data))
+tr.capture()
+for _ in range(10): tr.step_graph()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(100): tr.step_graph()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 100
+print('RW_GNN train step, graph replay: %.3f ms, %.2f M graphs/s, loss %.4f' % (dt * 1e3, 1024 / dt / 1e6, float(tr.loss)))
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
     for _ in range(5): step()

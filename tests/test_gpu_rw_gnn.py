@@ -100,3 +100,31 @@ def test_rw_gnn_interface_and_dropout(dev):
     mn = RW_GNN(2, 2, 16, 5, 4, 32, True, 2, 0.0, dev).to(dev)
     with pytest.raises(RuntimeError):
         mn.rw_features(data)
+
+
+def test_rw_gnn_graph_replay_trains_like_eager(dev):
+    """The training step of RW_GNN captured as a HIP graph (gnn_amd.trainer.Trainer with a forward callable)
+    follows the eagerly launched one."""
+    from gnn_amd.rw_gnn import RW_GNN
+    from gnn_amd.trainer import Trainer
+    x, ei, batch = _batch(9, 30, 2)
+    y = torch.from_numpy(np.random.default_rng(1).integers(0, 2, size=30)).to(dev)
+    data = RW_GNN.Data(torch.from_numpy(x).to(dev), torch.from_numpy(ei).to(dev), torch.from_numpy(batch).to(dev))
+
+    def make():
+        torch.manual_seed(4)
+        m = RW_GNN(2, 2, 16, 5, 4, 32, False, 2, 0.0, dev).to(dev)
+        m.train()
+        m(data)                                            # creates bn / fc1 / fc2
+        return Trainer(m, (None, None, None, y), 1, forward_fn=lambda: m(data))
+
+    eager, graph = make(), make()
+    for pe, pg in zip(eager.model.parameters(), graph.model.parameters()):
+        assert torch.equal(pe, pg)
+    graph.capture()
+    for _ in range(3):
+        eager.step_eager()
+    for _ in range(5):
+        eager.step_eager()
+        graph.step_graph()
+        assert abs(float(eager.loss.detach()) - float(graph.loss.detach())) < 1e-4 * abs(float(eager.loss.detach()))
