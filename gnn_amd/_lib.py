@@ -42,6 +42,10 @@ SIGNATURES = {
     "rwk_fused_backward_workspace": (_I64, [_I64, _I64, _I64, _I64, _I64]),
     "rwk_fused_path": (c_int, [_I64, _I64, _I64, _I64]),
     "rwk_fused_stream_len": (_I64, [_I64, _I64, _I64, _I64, _I64, c_int]),
+    "rwk_fused_keep_s_supported": (c_int, [_I64, _I64, _I64, _I64]),
+    "rwk_fused_forward_keep_s": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_float, _P, _P, _P]),
+    "rwk_fused_backward_keep_s": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_float, _P, _P, _P,
+                                          _P]),
     "rwk_head_supported": (c_int, [_I64, _I64, _I64, _I64]),
     "rwk_head_n_blocks": (_I64, [_I64]),
     "rwk_head_stats_size": (_I64, [_I64, _I64]),

@@ -677,6 +677,51 @@ int rwk_fused_backward(const float *x, const float *z, const int32_t *gid, const
     }
 }
 
+int rwk_fused_keep_s_supported(int64_t d, int64_t h, int64_t s, int64_t max_step) {
+    return rwk_reg::keep_s_supported(d, h, s, max_step) ? 1 : 0;
+}
+
+int rwk_fused_forward_keep_s(const float *x, const float *z, const int32_t *gid, const int32_t *perm, int64_t n,
+                             int64_t d, int64_t h, int64_t s, int64_t max_step, int64_t stream_len, float drop_p,
+                             const uint64_t *rng, float *k_partials, rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(x);
+    RWK_REQUIRE_PTR(z);
+    RWK_REQUIRE_PTR(gid);
+    RWK_REQUIRE_PTR(k_partials);
+    if (!sizes_ok(n, d, h, s, max_step, stream_len) || !(drop_p >= 0.f && drop_p < 1.f)) return RWK_E_SIZE;
+    if (!rwk_reg::keep_s_supported(d, h, s, max_step)) return RWK_E_UNSUPPORTED;
+    rwk_reg::Args r{};
+    r.x = x; r.z = z; r.gid = gid; r.perm = perm;
+    r.n = (int)n; r.d = (int)d; r.h = (int)h; r.s = (int)s; r.max_step = (int)max_step;
+    r.stream_len = (int)stream_len; r.drop = drop_p > 0.f && rng != nullptr; r.rng = (const unsigned long long *)rng;
+    r.stream = (hipStream_t)stream; r.k_partials = k_partials; r.keep_s = true;
+    rwk_drop_thresholds(drop_p, &r.t0, &r.t1);
+    return rwk_reg::forward(r);
+}
+
+int rwk_fused_backward_keep_s(const float *x, const float *z, const int32_t *gid, const int32_t *perm,
+                              const float *d_k, int64_t n, int64_t d, int64_t h, int64_t s, int64_t max_step,
+                              int64_t stream_len, float drop_p, const uint64_t *rng, float *dx, float *dz_partials,
+                              rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(x);
+    RWK_REQUIRE_PTR(z);
+    RWK_REQUIRE_PTR(gid);
+    RWK_REQUIRE_PTR(d_k);
+    RWK_REQUIRE_PTR(dx);
+    RWK_REQUIRE_PTR(dz_partials);
+    if (!sizes_ok(n, d, h, s, max_step, stream_len) || !(drop_p >= 0.f && drop_p < 1.f)) return RWK_E_SIZE;
+    if (!rwk_reg::keep_s_supported(d, h, s, max_step)) return RWK_E_UNSUPPORTED;
+    rwk_reg::Args r{};
+    r.x = x; r.z = z; r.gid = gid; r.perm = perm;
+    r.n = (int)n; r.d = (int)d; r.h = (int)h; r.s = (int)s; r.max_step = (int)max_step;
+    r.stream_len = (int)stream_len; r.drop = drop_p > 0.f && rng != nullptr; r.rng = (const unsigned long long *)rng;
+    r.stream = (hipStream_t)stream; r.d_k = d_k; r.counts_f32 = nullptr;
+    r.scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f; r.normalize = 0;
+    r.dx = dx; r.dz_partials = dz_partials; r.keep_s = true;
+    rwk_drop_thresholds(drop_p, &r.t0, &r.t1);
+    return rwk_reg::backward(r);
+}
+
 int rwk_dropout_mask(const uint64_t *rng, int64_t n, int64_t h, int64_t s, int64_t max_step, float drop_p,
                      uint8_t *keep, rwk_stream_t stream) {
     RWK_REQUIRE_PTR(rng);

@@ -20,10 +20,14 @@ struct Args {
     float scale;
     int normalize;
     float *dx, *dz_partials;
+    // features (and their gradients) per hidden node instead of summed over the hidden nodes
+    bool keep_s;
 };
 
 // true when (d, h, s, max_step) has a compiled register-resident instance
 bool supported(int64_t d, int64_t h, int64_t s, int64_t max_step);
+// true when the keep-S variant of (d, h, s, max_step) is compiled
+bool keep_s_supported(int64_t d, int64_t h, int64_t s, int64_t max_step);
 // workgroups of the backward launch = rows of dz_partials
 int64_t backward_blocks(int64_t n, int64_t stream_len, int64_t h);
 // positions per stream that fill the chip in whole rounds of resident workgroups

@@ -165,7 +165,9 @@ __device__ inline void load_tile(Tile<LT> &tile, const float *__restrict__ x, co
 }
 
 // HPT: lanes per stream as a compile-time constant (0 = use the run-time value hp_arg)
-template <int LT, int ST, bool DROP, int HPT>
+// KS (keep S): the sums over the hidden nodes are not taken; slot layout [(i * h + lane) * ST + s], L*H*ST floats
+// per slot, i.e. one feature per (step, hidden graph, hidden node) - the output of rwgnn/rwgnn_pyg.py:138-149.
+template <int LT, int ST, bool DROP, int HPT, bool KS = false>
 __global__ void __launch_bounds__(kBlock)
 forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const int *__restrict__ gid,
                const int *__restrict__ perm, int n, int d, int h, int stream_len, int hp_arg, uint32_t t0,
@@ -189,10 +191,20 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
     const int lh = LT * h;
     const size_t step_stride = (size_t)n * d;
 
-    float acc[LT];
+    constexpr int SK = KS ? ST : 1;                 // accumulators per step
+    float acc[LT][SK];
 #pragma unroll
-    for (int i = 0; i < LT; ++i) acc[i] = 0.f;
+    for (int i = 0; i < LT; ++i)
+#pragma unroll
+        for (int q = 0; q < SK; ++q) acc[i][q] = 0.f;
     int g_cur = -1;
+    auto flush = [&](int g) {
+        float *dst = k_partials + ((size_t)(c + g) * lh + lane_h) * SK;
+#pragma unroll
+        for (int i = 0; i < LT; ++i)
+#pragma unroll
+            for (int q = 0; q < SK; ++q) dst[(size_t)i * h * SK + q] = acc[i][q];
+    };
 
     for (int base = 0; base < stream_len; base += hp) {
         __syncthreads();
@@ -203,13 +215,11 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
             const int node = tile.node[group0 + j];
             const int g = tile.gid[group0 + j];
             if (g != g_cur) {
-                if (g_cur >= 0 && lane_h < h) {
-                    float *dst = k_partials + (size_t)(c + g_cur) * lh + lane_h;
+                if (g_cur >= 0 && lane_h < h) flush(g_cur);
 #pragma unroll
-                    for (int i = 0; i < LT; ++i) dst[i * h] = acc[i];
-                }
+                for (int i = 0; i < LT; ++i)
 #pragma unroll
-                for (int i = 0; i < LT; ++i) acc[i] = 0.f;
+                    for (int q = 0; q < SK; ++q) acc[i][q] = 0.f;
                 g_cur = g;
             }
             float xr[LT][DP];
@@ -220,9 +230,11 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
             }
             Keep<NC> keep;
             if (DROP) keep.draw(cfg, (uint32_t)node, (uint32_t)lane_h);
-            float node_acc[LT];
+            float node_acc[LT][SK];
 #pragma unroll
-            for (int i = 0; i < LT; ++i) node_acc[i] = 0.f;
+            for (int i = 0; i < LT; ++i)
+#pragma unroll
+                for (int q = 0; q < SK; ++q) node_acc[i][q] = 0.f;
 #pragma unroll
             for (int ss = 0; ss < ST; ++ss) {
                 const float zx = dot4(zr[0][ss], xr[0]);
@@ -231,21 +243,20 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
                     const float t = i == 0 ? zx : dot4(zr[i][ss], xr[i]);
                     float prod = zx * t;
                     if (DROP) prod = keep.at(ss * LT + i) ? prod : 0.f;
-                    node_acc[i] += prod;
+                    node_acc[i][KS ? ss : 0] += prod;
                 }
             }
 #pragma unroll
-            for (int i = 0; i < LT; ++i) acc[i] += node_acc[i];
+            for (int i = 0; i < LT; ++i)
+#pragma unroll
+                for (int q = 0; q < SK; ++q) acc[i][q] += node_acc[i][q];
         }
     }
-    if (g_cur >= 0 && lane_h < h) {
-        float *dst = k_partials + (size_t)(c + g_cur) * lh + lane_h;
-#pragma unroll
-        for (int i = 0; i < LT; ++i) dst[i * h] = acc[i];
-    }
+    if (g_cur >= 0 && lane_h < h) flush(g_cur);
 }
 
-template <int LT, int ST, bool DROP, int HPT>
+// KS: d_k holds one value per (step, hidden graph, hidden node), layout as the forward kernel's slots.
+template <int LT, int ST, bool DROP, int HPT, bool KS = false>
 __global__ void __launch_bounds__(kBlock, bwd_waves_per_simd(LT * ST))
 backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const int *__restrict__ gid,
                 const int *__restrict__ perm, const float *__restrict__ d_k, const float *__restrict__ counts_f32,
@@ -280,9 +291,12 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     float dz[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) dz[v] = 0.f;
-    float dp_cur[LT];
+    constexpr int SK = KS ? ST : 1;
+    float dp_cur[LT][SK];
 #pragma unroll
-    for (int i = 0; i < LT; ++i) dp_cur[i] = 0.f;
+    for (int i = 0; i < LT; ++i)
+#pragma unroll
+        for (int q = 0; q < SK; ++q) dp_cur[i][q] = 0.f;
     int g_cur = -1;
 
     // where this lane puts its dX total of the halving reduction: float (idx % 4) of row (idx / 4) of slot group0 + j
@@ -318,7 +332,9 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                 if (normalize) f /= counts_f32[g];
 #pragma unroll
                 for (int i = 0; i < LT; ++i)
-                    dp_cur[i] = own_h ? d_k[(size_t)g * lh + i * h + lane_h] * f : 0.f;
+#pragma unroll
+                    for (int q = 0; q < SK; ++q)
+                        dp_cur[i][q] = own_h ? d_k[((size_t)g * lh + i * h + lane_h) * SK + q] * f : 0.f;
             }
             // no validity branch: a slot past the end of the stream has x = 0, so zx = t = 0 and every
             // product below is zero
@@ -331,7 +347,7 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                     float w[LT];
 #pragma unroll
                     for (int i = 0; i < LT; ++i) {
-                        w[i] = dp_cur[i];
+                        w[i] = dp_cur[i][KS ? ss : 0];
                         if (DROP) w[i] = keep.at(ss * LT + i) ? w[i] : 0.f;
                     }
                     float dzx = 2.f * w[0] * zx;          // step 0 contributes keep * zx^2
@@ -423,6 +439,9 @@ inline int pow2_ceil(int v) {
     return p;
 }
 
+// keep-S instances: sixteen-lane layout, at most 20 (step, hidden node) accumulators per lane
+constexpr bool keep_s_built(int lt, int st) { return st > 1 && lt * st <= 20; }
+
 template <int LT, int ST>
 int launch_fwd(const Args &a) {
     const int hp = pow2_ceil(a.h);
@@ -431,7 +450,19 @@ int launch_fwd(const Args &a) {
 #define RWK_FWD(DROPV, HPV)                                                                                       \
     hipLaunchKernelGGL((forward_kernel<LT, ST, DROPV, HPV>), grid, dim3(kBlock), 0, a.stream, a.x, a.z, a.gid, a.perm, \
                        a.n, a.d, a.h, a.stream_len, hp, a.t0, a.t1, a.rng, a.k_partials)
-    if (hp == 16) { if (a.drop) RWK_FWD(true, 16); else RWK_FWD(false, 16); }
+    if (a.keep_s) {
+        if constexpr (keep_s_built(LT, ST)) {
+            if (hp != 16) return RWK_E_UNSUPPORTED;
+            if (a.drop)
+                hipLaunchKernelGGL((forward_kernel<LT, ST, true, 16, true>), grid, dim3(kBlock), 0, a.stream, a.x, a.z,
+                                   a.gid, a.perm, a.n, a.d, a.h, a.stream_len, hp, a.t0, a.t1, a.rng, a.k_partials);
+            else
+                hipLaunchKernelGGL((forward_kernel<LT, ST, false, 16, true>), grid, dim3(kBlock), 0, a.stream, a.x, a.z,
+                                   a.gid, a.perm, a.n, a.d, a.h, a.stream_len, hp, a.t0, a.t1, a.rng, a.k_partials);
+        } else {
+            return RWK_E_UNSUPPORTED;
+        }
+    } else if (hp == 16) { if (a.drop) RWK_FWD(true, 16); else RWK_FWD(false, 16); }
     else { if (a.drop) RWK_FWD(true, 0); else RWK_FWD(false, 0); }
 #undef RWK_FWD
     RWK_LAUNCH_CHECK();
@@ -446,7 +477,21 @@ int launch_bwd(const Args &a) {
     hipLaunchKernelGGL((backward_kernel<LT, ST, DROPV, HPV>), grid, dim3(kBlock), 0, a.stream, a.x, a.z, a.gid, a.perm, \
                        a.d_k, a.counts_f32, a.n, a.d, a.h, a.stream_len, hp, a.scale, a.normalize, a.t0, a.t1, a.rng, \
                        a.dx, a.dz_partials)
-    if (hp == 16) { if (a.drop) RWK_BWD(true, 16); else RWK_BWD(false, 16); }
+    if (a.keep_s) {
+        if constexpr (keep_s_built(LT, ST)) {
+            if (hp != 16) return RWK_E_UNSUPPORTED;
+            if (a.drop)
+                hipLaunchKernelGGL((backward_kernel<LT, ST, true, 16, true>), grid, dim3(kBlock), 0, a.stream, a.x, a.z,
+                                   a.gid, a.perm, a.d_k, a.counts_f32, a.n, a.d, a.h, a.stream_len, hp, a.scale,
+                                   a.normalize, a.t0, a.t1, a.rng, a.dx, a.dz_partials);
+            else
+                hipLaunchKernelGGL((backward_kernel<LT, ST, false, 16, true>), grid, dim3(kBlock), 0, a.stream, a.x,
+                                   a.z, a.gid, a.perm, a.d_k, a.counts_f32, a.n, a.d, a.h, a.stream_len, hp, a.scale,
+                                   a.normalize, a.t0, a.t1, a.rng, a.dx, a.dz_partials);
+        } else {
+            return RWK_E_UNSUPPORTED;
+        }
+    } else if (hp == 16) { if (a.drop) RWK_BWD(true, 16); else RWK_BWD(false, 16); }
     else { if (a.drop) RWK_BWD(true, 0); else RWK_BWD(false, 0); }
 #undef RWK_BWD
     RWK_LAUNCH_CHECK();
@@ -482,6 +527,10 @@ int by_l(const Args &a, bool bwd) {
 bool supported(int64_t d, int64_t h, int64_t s, int64_t max_step) {
     if (d < 1 || d > DP || h < 1 || h > 64 || max_step < 1 || max_step > 4) return false;
     return s == 1 || s == 3 || s == 4 || s == 5 || s == 6 || s == 8 || s == 10;
+}
+
+bool keep_s_supported(int64_t d, int64_t h, int64_t s, int64_t max_step) {
+    return supported(d, h, s, max_step) && pow2_ceil((int)h) == 16 && keep_s_built((int)max_step, (int)s);
 }
 
 int64_t backward_blocks(int64_t n, int64_t stream_len, int64_t h) {

@@ -2,9 +2,10 @@
 a ``Linear`` per step, and random-walk-kernel features kept per hidden NODE (G x H*S per step instead of G x H).
 
 Kept per hidden node, the feature of (hidden graph h, hidden node s) is what the fused kernels compute for a
-hidden graph of size one whose only row is ``Z_i[h, s]``: the H*S pairs are therefore handed to the same kernels as
-H*S one-node hidden graphs, up to sixty-four at a launch (fewer, larger launches beat the sixteen-lane kernel
-instances here: the step is bound by the host's launch rate).  The hidden-graph chain
+hidden graph of size one whose only row is ``Z_i[h, s]``.  Two ways to get them: keep-S instances of the fused kernels
+(hidden_dim <= 4, 9..16 hidden graphs, L*S <= 20: one launch each way, the lane of a hidden graph keeps its S sums
+apart), and, for every other shape, the H*S pairs handed to the ordinary kernels as one-node hidden graphs, up to
+sixty-four at a launch.  The hidden-graph chain
 ``Z_i = Ah Z_{i-1}`` and its backward are the usual kernels on the real H x S graphs; the node features of the steps
 (``x_i = lin_i(M x_{i-1})``) are built by autograd from :mod:`gnn_amd.rwconv` and enter the fused kernels as a
 stack, whose gradient they return.
@@ -72,6 +73,11 @@ def hidden_chain(adj_hidden, features_hidden, steps: int):
     return _HiddenChain.apply(adj_hidden, features_hidden, steps)
 
 
+#: use the keep-S kernel instances where they are built (False: always the one-node-hidden-graph formulation; the
+#: tests compare the two)
+KEEP_S_KERNELS = True
+
+
 def _chunk(d: int) -> int:
     """Pairs per launch: the kernels' limit on hidden graphs."""
     return 64
@@ -99,9 +105,23 @@ class _PairKernels(torch.autograd.Function):
         z_pairs = z.detach().reshape(steps, pairs, 1, d)
         k = torch.empty((g, steps, pairs), dtype=torch.float32, device=dev)
         chunks = []
+        keep_s = bool(lib.rwk_fused_keep_s_supported(d, h, s, steps)) and KEEP_S_KERNELS
         with _lib.device_guard(dev):
             stream = _lib.current_stream(dev)
-            for c, a in enumerate(range(0, pairs, _chunk(d))):
+            if keep_s:                                     # one launch on the real H x S hidden graphs
+                zc = z.detach().contiguous().float()
+                stream_len = choose_stream_len(n, d, h, s, steps)
+                k_part = torch.empty(lib.rwk_fused_k_partials_size(n, stream_len, g, pairs, steps),
+                                     dtype=torch.float32, device=dev)
+                _lib.check(lib.rwk_fused_forward_keep_s(xs_c.data_ptr(), zc.data_ptr(), st.gid.data_ptr(),
+                                                        _lib.ptr(st.perm), n, d, h, s, steps, stream_len, drop,
+                                                        _lib.ptr(rng_used) if drop else None, k_part.data_ptr(),
+                                                        stream), "rwk_fused_forward_keep_s")
+                _lib.check(lib.rwk_fused_reduce(k_part.data_ptr(), st.seg_ptr.data_ptr(), st.counts_f32.data_ptr(), g,
+                                                pairs, steps, stream_len, drop, 0, k.data_ptr(), stream),
+                           "rwk_fused_reduce")
+                chunks.append((0, pairs, zc, rng_used if drop else None))
+            for c, a in enumerate(range(0, 0 if keep_s else pairs, _chunk(d))):
                 b = min(a + _chunk(d), pairs)
                 hq = b - a
                 zc = z_pairs[:, a:b].contiguous()
@@ -121,7 +141,7 @@ class _PairKernels(torch.autograd.Function):
                            "rwk_fused_reduce")
                 k[:, :, a:b] = kc.view(g, steps, hq)
                 chunks.append((a, b, zc, rng_c))
-        ctx.st, ctx.drop, ctx.chunks, ctx.shape_z = st, drop, chunks, tuple(z.shape)
+        ctx.st, ctx.drop, ctx.chunks, ctx.shape_z, ctx.keep_s = st, drop, chunks, tuple(z.shape), keep_s
         ctx.save_for_backward(xs_c)
         return k
 
@@ -139,6 +159,17 @@ class _PairKernels(torch.autograd.Function):
         dz = torch.empty((steps, h * s, 1, d), dtype=torch.float32, device=dev)
         with _lib.device_guard(dev):
             stream = _lib.current_stream(dev)
+            if ctx.keep_s:
+                _, _, zc, rng_c = ctx.chunks[0]
+                stream_len = choose_stream_len(n, d, h, s, steps, backward=True)
+                n_part = lib.rwk_fused_dz_partials_count(n, stream_len, d, h, s, steps)
+                dz_part = torch.empty((n_part, steps * h * s * d), dtype=torch.float32, device=dev)
+                dx = torch.empty_like(xs_c)
+                _lib.check(lib.rwk_fused_backward_keep_s(xs_c.data_ptr(), zc.data_ptr(), st.gid.data_ptr(),
+                                                         _lib.ptr(st.perm), d_k.data_ptr(), n, d, h, s, steps,
+                                                         stream_len, drop, _lib.ptr(rng_c), dx.data_ptr(),
+                                                         dz_part.data_ptr(), stream), "rwk_fused_backward_keep_s")
+                return dx, _reduce_rows(lib, dz_part, stream).view(steps, h, s, d), None, None, None
             for a, b, zc, rng_c in ctx.chunks:
                 hq = b - a
                 stream_len = choose_stream_len(n, d, hq, 1, steps, backward=True)

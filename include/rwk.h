@@ -211,6 +211,22 @@ int rwk_fused_path(int64_t d, int64_t h, int64_t s, int64_t max_step);
  * partial-buffer sizes above must be queried with the value actually passed. */
 int64_t rwk_fused_stream_len(int64_t n, int64_t d, int64_t h, int64_t s, int64_t max_step, int backward);
 
+/* Keep-S variants (rwgnn/rwgnn_pyg.py:132-149: the features of that model are kept per hidden NODE):
+ *   K[g, (i*H + h)*S + s] = 1/(1-p) * sum_{p in g} m[i,h,s,n] * (Z0[h,s].X0[n]) * (Zi[h,s].Xi[n])
+ * k_partials has rwk_fused_k_partials_size(n, stream_len, G, H*S, L) floats and is reduced with
+ * rwk_fused_reduce(..., h = H*S, ..., normalize = 0, ...); d_k is (G, L*H*S) in the same column order; dx, dz_partials
+ * and the dropout mask are those of rwk_fused_backward (rwk_fused_dz_partials_count rows).  Built for hidden_dim <= 4,
+ * 9..16 hidden graphs, S > 1 and L*S <= 20 (rwk_fused_keep_s_supported); other shapes can treat every
+ * (hidden graph, hidden node) pair as a hidden graph of size one and use the entry points above. */
+int rwk_fused_keep_s_supported(int64_t d, int64_t h, int64_t s, int64_t max_step);
+int rwk_fused_forward_keep_s(const float *x, const float *z, const int32_t *gid, const int32_t *perm, int64_t n,
+                             int64_t d, int64_t h, int64_t s, int64_t max_step, int64_t stream_len,
+                             float drop_p, const uint64_t *rng, float *k_partials, rwk_stream_t stream);
+int rwk_fused_backward_keep_s(const float *x, const float *z, const int32_t *gid, const int32_t *perm,
+                              const float *d_k, int64_t n, int64_t d, int64_t h, int64_t s, int64_t max_step,
+                              int64_t stream_len, float drop_p, const uint64_t *rng, float *dx,
+                              float *dz_partials, rwk_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Classifier head   log_softmax(fc2(dropout(relu(fc1(bn(K))))))     replaces model.py:68-72
  * (BatchNorm1d, Linear, ReLU, Dropout, Linear, log_softmax) and their backward: two launches

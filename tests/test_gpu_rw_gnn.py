@@ -128,3 +128,32 @@ def test_rw_gnn_graph_replay_trains_like_eager(dev):
         eager.step_eager()
         graph.step_graph()
         assert abs(float(eager.loss.detach()) - float(graph.loss.detach())) < 1e-4 * abs(float(eager.loss.detach()))
+
+
+@pytest.mark.parametrize("h,s,d,steps", [(16, 5, 4, 2), (12, 3, 3, 4), (16, 10, 4, 2), (9, 4, 2, 1)])
+def test_keep_s_kernels_against_one_node_hidden_graphs(h, s, d, steps, dev):
+    """The keep-S kernel instances and the formulation as H*S one-node hidden graphs on the ordinary kernels give the
+    same features and gradients (to rounding: their streams cut the node range differently)."""
+    import gnn_amd.rw_gnn as R
+    from gnn_amd import _lib
+    from gnn_amd.rwconv import propagation_structure
+    assert _lib.load().rwk_fused_keep_s_supported(d, h, s, steps) == 1
+    x, ei, batch = _batch(h * s, 31, 1)
+    n = x.shape[0]
+    st = propagation_structure(torch.from_numpy(ei).to(dev), n, torch.from_numpy(batch).to(dev))
+    rng = np.random.default_rng(2)
+    xs0 = torch.from_numpy(rng.uniform(0, 1, size=(steps, n, d)).astype(np.float32)).to(dev)
+    z0 = torch.from_numpy(rng.uniform(0, 1, size=(steps, h, s, d)).astype(np.float32)).to(dev)
+    dk = torch.from_numpy(rng.normal(size=(st.n_graphs, steps, h * s)).astype(np.float32)).to(dev)
+    runs = []
+    try:
+        for flag in (True, False):
+            R.KEEP_S_KERNELS = flag
+            xs, z = xs0.clone().requires_grad_(True), z0.clone().requires_grad_(True)
+            k = R.pair_kernel_features(xs, z, st)
+            k.backward(dk)
+            runs.append((k.detach().cpu().numpy(), xs.grad.cpu().numpy(), z.grad.cpu().numpy()))
+    finally:
+        R.KEEP_S_KERNELS = True
+    for a, b in zip(*runs):
+        assert rel_err(a, b.astype(np.float64)) < 1e-5
