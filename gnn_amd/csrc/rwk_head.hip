@@ -50,7 +50,7 @@ struct FastDiv {
     __device__ inline int mod(int i) const { return i - div(i) * d; }
 };
 constexpr int kMaxBlocks = 256;
-constexpr int kMaxC = 256, kMaxNC = 32, kMaxPC = 4096;
+constexpr int kMaxC = 256, kMaxNC = 32, kMaxPC = 8192;
 constexpr uint32_t kHeadCall = 0xFFFFFFFFu;       // Philox counter word no other mask of the model uses
 
 __host__ __device__ inline int head_blocks(long long g) {

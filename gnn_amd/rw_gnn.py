@@ -23,6 +23,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .function import _reduce_rows, choose_stream_len
+from .head import fused_head, head_supported
 from .rwconv import RWConv, narrow_linear, propagation_structure
 from .structure import GraphStructure
 
@@ -230,6 +231,7 @@ class RW_GNN(nn.Module):
         self.sigmoid = nn.Sigmoid()
         self.init_weights()
         self._rng_state = None
+        self.fused_head = True           # False: the head runs on the torch modules' own operators
 
     def init_weights(self):                                   # rwgnn_pyg.py:90-92
         self.adj_hidden.data.uniform_(-1, 1)
@@ -274,10 +276,17 @@ class RW_GNN(nn.Module):
         dev = out.device
         if self.bn is None or self.bn.num_features != out.size(1):            # :156-164
             self.bn = nn.BatchNorm1d(out.size(1)).to(dev)
-        out = self.bn(out)
         if self.fc1 is None or self.fc1.in_features != out.size(1):
             self.fc1 = nn.Linear(out.size(1), self.penultimate_dim).to(dev)
             self.fc2 = nn.Linear(self.penultimate_dim, self.num_classes).to(dev)
+        if self.fused_head and out.is_cuda and isinstance(self.bn.momentum, float) and \
+                head_supported(out.size(0), out.size(1), self.penultimate_dim, self.num_classes):
+            # :159,166-170 in the fused head kernels (same modules and state_dict; own dropout generator)
+            p = self.dropout.p if self.training else 0.0
+            if self._rng_state is None or self._rng_state.device != dev:
+                self.seed_dropout(int(torch.randint(0, 2 ** 62, (1,)).item()))
+            return fused_head(out, self.bn, self.fc1, self.fc2, p, self.training, self._rng_state if p > 0 else None)
+        out = self.bn(out)
         out = self.relu(self.fc1(out))
         out = self.dropout(out)
         out = self.fc2(out)

@@ -231,7 +231,7 @@ int rwk_fused_backward_keep_s(const float *x, const float *z, const int32_t *gid
  * Classifier head   log_softmax(fc2(dropout(relu(fc1(bn(K))))))     replaces model.py:68-72
  * (BatchNorm1d, Linear, ReLU, Dropout, Linear, log_softmax) and their backward: two launches
  * each way instead of ~35.  K: (g, c) with c = max_step * hidden_graphs; w1: (p, c); w2: (nc, p).
- * Limits: c <= 256, nc <= 32, p * c <= 4096 (rwk_head_supported); callers outside them keep
+ * Limits: c <= 256, nc <= 32, p * c <= 8192 (rwk_head_supported); callers outside them keep
  * the torch modules.
  * ------------------------------------------------------------------------------------- */
 int rwk_head_supported(int64_t g, int64_t c, int64_t p, int64_t nc);

@@ -81,7 +81,7 @@ def reference(m64, k64, y, training, mask=None, scale=1.0):
 
 
 @pytest.mark.parametrize("g,c,p,nc", [(64, 32, 32, 2), (33, 32, 32, 2), (1000, 128, 32, 7), (9000, 48, 20, 3),
-                                      (2, 16, 8, 2), (257, 256, 16, 5)])
+                                      (2, 16, 8, 2), (257, 256, 16, 5), (700, 160, 32, 2), (300, 256, 32, 3)])
 @pytest.mark.parametrize("training", [True, False])
 def test_head_matches_torch_fp64(dev, g, c, p, nc, training):
     from gnn_amd.head import fused_head, head_supported
@@ -173,7 +173,7 @@ def test_head_dropout(dev):
 def test_head_limits_and_errors(dev):
     from gnn_amd.head import fused_head, head_supported
     assert not head_supported(10, 300, 8, 2)
-    assert not head_supported(10, 256, 32, 2)          # penultimate_dim * features > 4096
+    assert not head_supported(10, 256, 33, 2)          # penultimate_dim * features > 8192
     assert not head_supported(10, 32, 32, 40)
     m = make(8, 4, 2, 0).to(dev).train()
     with pytest.raises(ValueError):
