@@ -319,9 +319,17 @@ def main():
     model.seed_dropout(1234 + rank)
     broadcast_parameters(model)
     tr = Trainer(model, batch_t, world, args.optimizer, sync_before_all_reduce=backend != "nccl")
+    launch = args.mode
     if args.mode == "graph":
-        tr.capture()
-        step = tr.step_graph
+        try:
+            tr.capture()
+            step = tr.step_graph
+        except Exception as exc:        # a capture that the runtime refuses must not cost the whole measurement
+            print(f"[bench] HIP-graph capture failed ({type(exc).__name__}: {exc}); launching eagerly",
+                  file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            launch = "eager (capture failed)"
+            step = tr.step_eager
     else:
         step = tr.step_eager
 
@@ -366,7 +374,7 @@ def main():
                             f"(rank 0), H{hp['hidden_graphs']} S{hp['size_hidden_graphs']} D{hp['hidden_dim']} "
                             f"L{hp['max_step']} dropout {hp['dropout']}",
                 "step": "zero_grad + forward + cross_entropy + backward + grad all-reduce + Adam (%s)" % args.optimizer,
-                "launch": args.mode,
+                "launch": launch,
                 "parallelism": f"dp{world} (graphs sharded, one flat-bucket all-reduce)",
             },
             "final_loss": round(loss, 5),
