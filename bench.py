@@ -43,7 +43,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="proteins1024")
+    ap.add_argument("--config", default="proteins1024",
+                    help="synthetic workload of gnn_amd.synth.CONFIGS: proteins1024 (the metric's), stream_h64, "
+                         "powerlaw, single_graph (one graph: --kernels-only, a batch of one cannot train)")
     ap.add_argument("--scale", type=int, default=1, help="multiply the number of graphs per batch")
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
                     help="replay the step from a captured HIP graph (default) or launch it eagerly")
@@ -288,6 +290,8 @@ def main():
     from gnn_amd.dp import broadcast_parameters
     from gnn_amd.synth import CONFIGS, config_batch
 
+    if args.config not in CONFIGS:
+        raise SystemExit("unknown --config %r; choose from %s" % (args.config, ", ".join(CONFIGS)))
     cfg = CONFIGS[args.config]
     hp = dict(cfg["hp"])
     if args.dropout is not None:
@@ -312,6 +316,9 @@ def main():
               flush=True)
         return
 
+    if batch.n_graphs < 2:
+        raise SystemExit("%s is a batch of one graph: BatchNorm1d cannot train on it (model.py:68 raises in the "
+                         "reference too); run it with --kernels-only" % args.config)
     torch.manual_seed(0)
     model = RW_NN(hp["input_dim"], hp["max_step"], hp["hidden_graphs"], hp["size_hidden_graphs"], hp["hidden_dim"],
                   hp["penultimate_dim"], hp["normalize"], hp["n_classes"], hp["dropout"], dev).to(dev)
