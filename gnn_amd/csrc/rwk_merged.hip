@@ -73,7 +73,7 @@ int rwk_project_hidden_forward(const float *features, const float *weight, const
     if (n <= 0 || f <= 0 || d <= 0 || n >= 0x7FFFFFFFll / 4 || h <= 0 || s <= 0 || max_step <= 0 || h > 65535)
         return RWK_E_SIZE;
     if (s > 1) RWK_REQUIRE_PTR(adj_hidden);
-    if (d != 4 || f > 8 || ((uintptr_t)x0 & 15u) != 0) return RWK_E_UNSUPPORTED;
+    if (d != 4 || f > 16 || ((uintptr_t)x0 & 15u) != 0) return RWK_E_UNSUPPORTED;
     const size_t lds = hidden_forward_lds(s, d);
     const dim3 grid((unsigned)(h + rwk_ceil_div(n, kBlock)));
     hipStream_t stream = (hipStream_t)stream_;
@@ -89,7 +89,8 @@ int rwk_project_hidden_forward(const float *features, const float *weight, const
     if (f == 1) RWK_PHF(1);
     else if (f == 2) RWK_PHF(2);
     else if (f <= 4) RWK_PHF(4);
-    else RWK_PHF(8);
+    else if (f <= 8) RWK_PHF(8);
+    else RWK_PHF(16);
 #undef RWK_PHF
     RWK_LAUNCH_CHECK();
     return RWK_OK;
@@ -115,7 +116,7 @@ int rwk_project_hidden_backward(const float *dx0, const float *x0, const float *
         RWK_REQUIRE_PTR(adj_hidden);
         RWK_REQUIRE_PTR(d_adj_hidden);
     }
-    if (f > 8 || d > 64) return RWK_E_UNSUPPORTED;
+    if (f > 16 || d > 64) return RWK_E_UNSUPPORTED;
     const int dpad = project_pow2_ceil((int)d);
     const int64_t proj_blocks = rwk_project_backward_blocks(n, d);
     const int64_t n_slices = hidden_backward_slices(max_step * s * d, n_partials);
@@ -136,7 +137,8 @@ int rwk_project_hidden_backward(const float *dx0, const float *x0, const float *
     if (f == 1) RWK_PHB(1);
     else if (f == 2) RWK_PHB(2);
     else if (f <= 4) RWK_PHB(4);
-    else RWK_PHB(8);
+    else if (f <= 8) RWK_PHB(8);
+    else RWK_PHB(16);
 #undef RWK_PHB
     RWK_LAUNCH_CHECK();
     return RWK_OK;

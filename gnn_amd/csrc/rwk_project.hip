@@ -28,6 +28,45 @@ project_forward_kernel(const float *__restrict__ feat, const float *__restrict__
     x0[t] = SIGMOID ? 1.0f / (1.0f + expf(-acc)) : acc;
 }
 
+// hidden_dim up to 64 with the weights in registers: thread (slot, c) keeps row c of W and walks kRowNodes nodes;
+// the lanes of a node read the same feature addresses (one broadcast load each) and write one contiguous row.
+// The general kernel above reads W[c * f + k] per output: 64 cache lines per wavefront load at f = 16.
+constexpr int kRowNodes = 8;
+
+template <int FP, bool SIGMOID>
+__global__ void __launch_bounds__(kBlock)
+project_forward_rows_kernel(const float *__restrict__ feat, const float *__restrict__ w, const float *__restrict__ b,
+                            int n, int f, int d, int dpad, float *__restrict__ x0) {
+    const int c = threadIdx.x % dpad, slot = threadIdx.x / dpad, slots = kBlock / dpad;
+    const bool own = c < d;
+    const int cc = own ? c : d - 1;
+    float wr[FP];
+#pragma unroll
+    for (int k = 0; k < FP; ++k) wr[k] = k < f ? w[(size_t)cc * f + k] : 0.f;
+    const float bias = b[cc];
+    const long long first = ((long long)blockIdx.x * slots + slot) * kRowNodes;
+#pragma unroll
+    for (int u0 = 0; u0 < kRowNodes; u0 += 4) {
+        float fr[4][FP];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long node = first + u0 + u;
+            const long long nc = node < n ? node : n - 1;
+#pragma unroll
+            for (int k = 0; k < FP; ++k) fr[u][k] = feat[nc * f + (k < f ? k : f - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long node = first + u0 + u;
+            float acc = bias;
+#pragma unroll
+            for (int k = 0; k < FP; ++k)
+                if (k < f) acc = fmaf(fr[u][k], wr[k], acc);
+            if (own && node < n) x0[node * d + c] = SIGMOID ? 1.0f / (1.0f + expf(-acc)) : acc;
+        }
+    }
+}
+
 template <int FP, bool SIGMOID>
 __global__ void __launch_bounds__(kBlock)
 project_forward4_kernel(const float *__restrict__ feat, const float *__restrict__ w, const float *__restrict__ b,
@@ -170,7 +209,7 @@ static int project_forward_impl(const float *features, const float *weight, cons
     RWK_REQUIRE_PTR(x0);
     if (n <= 0 || f <= 0 || d <= 0 || n * d >= 0x7FFFFFFFll) return RWK_E_SIZE;
     hipStream_t s = (hipStream_t)stream;
-    if (d == 4 && f <= 8 && ((uintptr_t)x0 & 15u) == 0) {
+    if (d == 4 && f <= 16 && ((uintptr_t)x0 & 15u) == 0) {
         const dim3 grid((unsigned)rwk_ceil_div(n, kBlock));
 #define RWK_PF(FP)                                                                                                \
     hipLaunchKernelGGL((project_forward4_kernel<FP, SIGMOID>), grid, dim3(kBlock), 0, s, features, weight, bias, (int)n, \
@@ -178,8 +217,21 @@ static int project_forward_impl(const float *features, const float *weight, cons
         if (f == 1) RWK_PF(1);
         else if (f == 2) RWK_PF(2);
         else if (f <= 4) RWK_PF(4);
-        else RWK_PF(8);
+        else if (f <= 8) RWK_PF(8);
+        else RWK_PF(16);
 #undef RWK_PF
+    } else if (d <= 64 && f <= 16) {
+        const int dpad = pow2_ceil((int)d);
+        const dim3 grid((unsigned)rwk_ceil_div(n, (int64_t)(kBlock / dpad) * kRowNodes));
+#define RWK_PR(FP)                                                                                                \
+    hipLaunchKernelGGL((project_forward_rows_kernel<FP, SIGMOID>), grid, dim3(kBlock), 0, s, features, weight, bias, \
+                       (int)n, (int)f, (int)d, dpad, x0)
+        if (f == 1) RWK_PR(1);
+        else if (f == 2) RWK_PR(2);
+        else if (f <= 4) RWK_PR(4);
+        else if (f <= 8) RWK_PR(8);
+        else RWK_PR(16);
+#undef RWK_PR
     } else {
         hipLaunchKernelGGL((project_forward_kernel<SIGMOID>), dim3((unsigned)rwk_ceil_div(n * d, kBlock)), dim3(kBlock),
                            0, s, features, weight, bias, (int)n, (int)f, (int)d, x0);
@@ -221,7 +273,7 @@ static int project_backward_impl(const float *dx0, const float *x0, const float 
     RWK_REQUIRE_PTR(weight);
     RWK_REQUIRE_PTR(partials);
     if (n <= 0 || f <= 0 || d <= 0) return RWK_E_SIZE;
-    if (f > 8 || d > 64) return RWK_E_UNSUPPORTED;
+    if (f > 16 || d > 64) return RWK_E_UNSUPPORTED;
     const int dpad = pow2_ceil((int)d);
     const unsigned blocks = (unsigned)rwk_project_backward_blocks(n, d);
     hipStream_t s = (hipStream_t)stream;
@@ -232,7 +284,8 @@ static int project_backward_impl(const float *dx0, const float *x0, const float 
     if (f == 1) RWK_PB(1);
     else if (f == 2) RWK_PB(2);
     else if (f <= 4) RWK_PB(4);
-    else RWK_PB(8);
+    else if (f <= 8) RWK_PB(8);
+    else RWK_PB(16);
 #undef RWK_PB
     RWK_LAUNCH_CHECK();
     return RWK_OK;

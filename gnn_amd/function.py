@@ -5,7 +5,7 @@ batch graph and on the hidden graphs, the (H*S) x N contraction, dropout, produc
 sum, normalisation and concatenation) and their autograd backward.
 
 Two entry modes:
-* narrow inputs (``input_dim <= 8``, e.g. the node degree): the projection ``features @ W^T + b`` and its
+* narrow inputs (``input_dim <= 16``, e.g. the node degree): the projection ``features @ W^T + b`` and its
   weight/bias gradients run in our own streaming kernels (a GEMM library spends ~0.7 ms on the N-long
   reduction of a 4 x N by N x 1 product);
 * wide inputs: the caller applies ``fc`` with torch (a real GEMM) and passes the pre-activation.
@@ -21,7 +21,7 @@ from .structure import GraphStructure
 
 __all__ = ["rw_kernel_layer", "rw_kernel_layer_projected", "choose_stream_len", "FUSED_PROJECTION_MAX_INPUT_DIM"]
 
-FUSED_PROJECTION_MAX_INPUT_DIM = 8
+FUSED_PROJECTION_MAX_INPUT_DIM = 16
 #: launch the hidden-graph kernels together with the projection kernels they are independent of (one launch
 #: instead of two, forward and backward); False keeps the stand-alone launches (tests compare the two)
 MERGED_LAUNCHES = True

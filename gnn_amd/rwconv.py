@@ -85,7 +85,7 @@ def propagate(x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
 
 
 class _NarrowLinear(torch.autograd.Function):
-    """``x W^T + b`` for at most 8 input and 64 output channels (``rwgnn_pyg.py:46`` at the reference's widths):
+    """``x W^T + b`` for at most 16 input and 64 output channels (``rwgnn_pyg.py:46`` at the reference's widths):
     the narrow-input kernels of the input projection without their sigmoid, instead of a GEMM library's
     N x 4 times 4 x 4 product and its N-long weight-gradient reduction."""
 
@@ -125,7 +125,7 @@ class _NarrowLinear(torch.autograd.Function):
 
 def narrow_linear(x, weight, bias):
     """``F.linear(x, weight, bias)`` on the narrow-input kernels when they cover the widths, else torch's."""
-    if x.is_cuda and x.dim() == 2 and bias is not None and x.shape[1] <= 8 and weight.shape[0] <= 64 \
+    if x.is_cuda and x.dim() == 2 and bias is not None and x.shape[1] <= 16 and weight.shape[0] <= 64 \
             and x.shape[0] > 0:
         return _NarrowLinear.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)

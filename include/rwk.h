@@ -275,7 +275,7 @@ int rwk_cross_entropy_backward(const float *scores, const int64_t *labels, int64
 
 /* ---------------------------------------------------------------------------------------
  * Input projection  X0 = sigmoid(features W^T + b)   replaces model.py:43 for narrow inputs
- * (input_dim <= 8; wider inputs go through a GEMM library and only the sigmoid is applied here)
+ * (input_dim <= 16; wider inputs go through a GEMM library and only the sigmoid is applied here)
  * ------------------------------------------------------------------------------------- */
 
 /* features (n, f), weight (d, f), bias (d) -> x0 (n, d). */
@@ -287,12 +287,12 @@ int64_t rwk_project_backward_blocks(int64_t n, int64_t d);
 
 /* dx0 (n, d): gradient of x0.  partials (blocks, d*f + d): per-workgroup sums of
  * [dW (d, f) | db (d)], to be added row by row with rwk_reduce_rows.  d_features (n, f) is
- * written when non-null.  Requires f <= 8, d <= 64. */
+ * written when non-null.  Requires f <= 16, d <= 64. */
 int rwk_project_backward(const float *dx0, const float *x0, const float *features,
                          const float *weight, int64_t n, int64_t f, int64_t d, float *partials,
                          float *d_features, rwk_stream_t stream);
 
-/* The same two kernels without the sigmoid: y = x W^T + b for narrow inputs (f <= 8 input, d <= 64 output
+/* The same two kernels without the sigmoid: y = x W^T + b for narrow inputs (f <= 16 input, d <= 64 output
  * channels), the Linear inside RWConv (rwgnn/rwgnn_pyg.py:23,46) at hidden_dim 4, which a GEMM library serves
  * badly (N x 4 times 4 x 4, and an N-long reduction for the weight gradient).  Backward: per-workgroup partial
  * rows [dW (d, f) | db (d)] (rwk_project_backward_blocks(n, d) of them, add with rwk_reduce_rows) and d_x (n, f),
@@ -303,7 +303,7 @@ int rwk_linear_backward(const float *d_y, const float *x, const float *weight, i
                         float *partials, float *d_x, rwk_stream_t stream);
 
 /* rwk_hidden_forward and rwk_project_forward in ONE launch (model.py:39-43,56: neither depends on the other),
- * for hidden_dim d = 4 and f <= 8 input features (RWK_E_UNSUPPORTED otherwise: launch the two separately).
+ * for hidden_dim d = 4 and f <= 16 input features (RWK_E_UNSUPPORTED otherwise: launch the two separately).
  * Arguments and results as the two stand-alone entry points. */
 int rwk_project_hidden_forward(const float *features, const float *weight, const float *bias, int64_t n,
                                int64_t f, int64_t d, float *x0, const float *adj_hidden,
@@ -312,7 +312,7 @@ int rwk_project_hidden_forward(const float *features, const float *weight, const
                                rwk_stream_t stream);
 
 /* rwk_hidden_backward and rwk_project_backward in ONE launch (their inputs, the reduced dZ partials and
- * dx[0] after the SpMM chain, are both ready at that point of the backward pass); f <= 8, d <= 64. */
+ * dx[0] after the SpMM chain, are both ready at that point of the backward pass); f <= 16, d <= 64. */
 int rwk_project_hidden_backward(const float *dx0, const float *x0, const float *features,
                                 const float *weight, int64_t n, int64_t f, int64_t d, float *partials,
                                 float *d_features, const float *adj_hidden, const float *ah,

@@ -33,7 +33,8 @@ def test_reduce_rows(p, v, dev):
     assert torch.equal(out, out2)
 
 
-@pytest.mark.parametrize("n,f,d", [(1000, 1, 4), (777, 3, 6), (64, 8, 16), (5000, 2, 64)])
+@pytest.mark.parametrize("n,f,d", [(1000, 1, 4), (777, 3, 6), (64, 8, 16), (5000, 2, 64), (3000, 16, 64),
+                                   (901, 11, 4), (2500, 16, 4)])
 def test_projection_forward_backward(n, f, d, dev):
     from gnn_amd import _lib
     lib = _lib.load()
