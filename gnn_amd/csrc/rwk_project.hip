@@ -28,42 +28,51 @@ project_forward_kernel(const float *__restrict__ feat, const float *__restrict__
     x0[t] = SIGMOID ? 1.0f / (1.0f + expf(-acc)) : acc;
 }
 
-// hidden_dim up to 64 with the weights in registers: thread (slot, c) keeps row c of W and walks kRowNodes nodes;
-// the lanes of a node read the same feature addresses (one broadcast load each) and write one contiguous row.
-// The general kernel above reads W[c * f + k] per output: 64 cache lines per wavefront load at f = 16.
-constexpr int kRowNodes = 8;
+// hidden_dim up to 64 with the weights in registers: thread (slot, c) keeps row c of W and walks `rows` nodes.
+// The workgroup's feature rows are one contiguous range of memory: they are copied to LDS with coalesced loads
+// (rows padded to FP floats) and every thread reads its node's row from there.  Reading them from memory per
+// thread costs one address per lane for a value that dpad lanes share: at hidden_dim 64 the address unit, not
+// HBM, then bounds the kernel; the general kernel above is worse still (W[c * f + k] per output: 64 cache lines
+// per wavefront load at f = 16).
+constexpr int kRowTileFloats = 4096;                   // LDS tile: (nodes of a workgroup) x FP floats, 16 KB
+constexpr int kRowNodesMax = 32;                      // amortises the strided load of the weight row
+
+inline int project_rows_per_slot(int slots, int fp) {
+    int rows = kRowTileFloats / (slots * fp);
+    return rows > kRowNodesMax ? kRowNodesMax : (rows < 1 ? 1 : rows);
+}
 
 template <int FP, bool SIGMOID>
 __global__ void __launch_bounds__(kBlock)
 project_forward_rows_kernel(const float *__restrict__ feat, const float *__restrict__ w, const float *__restrict__ b,
-                            int n, int f, int d, int dpad, float *__restrict__ x0) {
+                            int n, int f, int d, int dpad, int rows, float *__restrict__ x0) {
+    __shared__ __attribute__((aligned(16))) float tile[kRowTileFloats];
     const int c = threadIdx.x % dpad, slot = threadIdx.x / dpad, slots = kBlock / dpad;
     const bool own = c < d;
     const int cc = own ? c : d - 1;
+    const long long first = (long long)blockIdx.x * slots * rows;          // first node of the workgroup
+    const long long left = (long long)n - first;
+    const int nodes = (int)(left < (long long)slots * rows ? left : (long long)slots * rows);
+    const float inv_f = 1.0f / (float)f;
+    for (int i = threadIdx.x; i < nodes * f; i += kBlock) {
+        const int r = (int)(((float)i + 0.5f) * inv_f);                     // i / f, exact for i < 2^17
+        tile[r * FP + (i - r * f)] = feat[first * f + i];
+    }
     float wr[FP];
 #pragma unroll
     for (int k = 0; k < FP; ++k) wr[k] = k < f ? w[(size_t)cc * f + k] : 0.f;
     const float bias = b[cc];
-    const long long first = ((long long)blockIdx.x * slots + slot) * kRowNodes;
+    __syncthreads();
+    for (int u = 0; u < rows; ++u) {
+        const int local = slot * rows + u;
+        if (local >= nodes) break;
+        float fr[FP];                                     // whole padded row: the padding is never used below
 #pragma unroll
-    for (int u0 = 0; u0 < kRowNodes; u0 += 4) {
-        float fr[4][FP];
+        for (int k = 0; k < FP; ++k) fr[k] = tile[local * FP + k];
+        float acc = bias;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long long node = first + u0 + u;
-            const long long nc = node < n ? node : n - 1;
-#pragma unroll
-            for (int k = 0; k < FP; ++k) fr[u][k] = feat[nc * f + (k < f ? k : f - 1)];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long long node = first + u0 + u;
-            float acc = bias;
-#pragma unroll
-            for (int k = 0; k < FP; ++k)
-                if (k < f) acc = fmaf(fr[u][k], wr[k], acc);
-            if (own && node < n) x0[node * d + c] = SIGMOID ? 1.0f / (1.0f + expf(-acc)) : acc;
-        }
+        for (int k = 0; k < FP; ++k) acc = k < f ? fmaf(fr[k], wr[k], acc) : acc;
+        if (own) x0[(first + local) * d + c] = SIGMOID ? 1.0f / (1.0f + expf(-acc)) : acc;
     }
 }
 
@@ -221,11 +230,13 @@ static int project_forward_impl(const float *features, const float *weight, cons
         else RWK_PF(16);
 #undef RWK_PF
     } else if (d <= 64 && f <= 16) {
-        const int dpad = pow2_ceil((int)d);
-        const dim3 grid((unsigned)rwk_ceil_div(n, (int64_t)(kBlock / dpad) * kRowNodes));
+        const int dpad = pow2_ceil((int)d), slots = kBlock / dpad;
+        const int fp = f == 1 ? 1 : f == 2 ? 2 : f <= 4 ? 4 : f <= 8 ? 8 : 16;
+        const int rows = project_rows_per_slot(slots, fp);
+        const dim3 grid((unsigned)rwk_ceil_div(n, (int64_t)slots * rows));
 #define RWK_PR(FP)                                                                                                \
     hipLaunchKernelGGL((project_forward_rows_kernel<FP, SIGMOID>), grid, dim3(kBlock), 0, s, features, weight, bias, \
-                       (int)n, (int)f, (int)d, dpad, x0)
+                       (int)n, (int)f, (int)d, dpad, rows, x0)
         if (f == 1) RWK_PR(1);
         else if (f == 2) RWK_PR(2);
         else if (f <= 4) RWK_PR(4);
