@@ -54,6 +54,10 @@ SIGNATURES = {
                                  _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "rwk_head_backward": (c_int, [_P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_float,
                                   _P, _P, _P, _P, _P]),
+    "rwk_head_forward_loss": (c_int, [_P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, c_float, c_float, c_int, _P,
+                                      _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "rwk_head_backward_loss": (c_int, [_P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_float,
+                                       _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rwk_cross_entropy_forward": (c_int, [_P, _P, _I64, _I64, _P, _P]),
     "rwk_cross_entropy_backward": (c_int, [_P, _P, _I64, _I64, _P, _P, _P]),
     "rwk_project_forward": (c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),

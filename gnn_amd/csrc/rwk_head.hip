@@ -231,6 +231,15 @@ struct HeadDims {
     int c, p, nc;
 };
 
+// log sum exp of one row of scores
+__device__ inline float row_lse(const float *__restrict__ x, int nc) {
+    float mx = x[0];
+    for (int q = 1; q < nc; ++q) mx = fmaxf(mx, x[q]);
+    float se = 0.f;
+    for (int q = 0; q < nc; ++q) se += expf(x[q] - mx);
+    return mx + logf(se);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
@@ -241,10 +250,12 @@ head_apply_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
                   const float *__restrict__ partials, int n_partials, const float *__restrict__ w1,
                   const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2,
                   float drop_p, const unsigned long long *__restrict__ rng, float *__restrict__ mean_out,
-                  float *__restrict__ invstd_out, float *__restrict__ h1d_out, float *__restrict__ out) {
+                  float *__restrict__ invstd_out, float *__restrict__ h1d_out, float *__restrict__ out,
+                  const long long *__restrict__ labels, float *__restrict__ loss_partials) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int c = dm.c, p = dm.p, nc = dm.nc;
     const int cs = c + 1, ps = p + 1;
+    float nll = 0.f;                         // labels given: -log p(label) of this thread's rows, over the tiles
     float *s_w1 = lds;                       // [p][cs]
     float *s_w2 = s_w1 + p * cs;             // [nc][ps]
     float *s_b1 = s_w2 + nc * ps;            // [p]
@@ -376,9 +387,28 @@ head_apply_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
             for (int q = 0; q < nc; ++q) se += expf(o[q] - mx);
             const float lse = mx + logf(se);
             for (int q = 0; q < nc; ++q) out[(r0 + tid) * nc + q] = o[q] - lse;
+            if (labels != nullptr) {
+                // cross-entropy of the stored log-probabilities x = o - lse, as the stand-alone kernel computes it
+                float mx2 = o[0] - lse;
+                for (int q = 1; q < nc; ++q) mx2 = fmaxf(mx2, o[q] - lse);
+                float se2 = 0.f;
+                for (int q = 0; q < nc; ++q) se2 += expf((o[q] - lse) - mx2);
+                long long cls = labels[r0 + tid];
+                cls = cls < 0 ? 0 : (cls >= nc ? nc - 1 : cls);
+                nll += (mx2 + logf(se2)) - (o[cls] - lse);
+            }
         }
         __syncthreads();
         HEAD_STAMP_AT(4);
+    }
+    if (labels != nullptr) {                 // this block's share of the loss sum: its kRows row lanes in order
+        if (tid < kRows) s_y[tid] = nll;
+        __syncthreads();
+        if (tid == 0) {
+            float acc = 0.f;
+            for (int r = 0; r < kRows; ++r) acc += s_y[r];
+            loss_partials[blockIdx.x] = acc;
+        }
     }
 }
 
@@ -393,7 +423,9 @@ head_bwd_tile_kernel(const float *__restrict__ k, HeadDims dm, const float *__re
                      const float *__restrict__ bn_b, const float *__restrict__ mean, const float *__restrict__ invstd,
                      const float *__restrict__ w1, const float *__restrict__ w2, const float *__restrict__ h1d,
                      const float *__restrict__ out, const float *__restrict__ d_out, float keep_scale,
-                     float *__restrict__ dy, float *__restrict__ partials) {
+                     float *__restrict__ dy, float *__restrict__ partials, const long long *__restrict__ labels,
+                     const float *__restrict__ d_loss, const float *__restrict__ loss_partials, int n_loss_partials,
+                     float *__restrict__ loss_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int c = dm.c, p = dm.p, nc = dm.nc;
     const int cs = c + 1, ps = p + 1;
@@ -439,11 +471,24 @@ head_bwd_tile_kernel(const float *__restrict__ k, HeadDims dm, const float *__re
             t_mu[u] = mean[col];
             t_is[u] = invstd[col];
         }
-        if (tid < nr) {                                  // log-softmax backward, one row per thread
+        if (tid < nr && labels == nullptr) {             // log-softmax backward, one row per thread
             const float *go = d_out + (r0 + tid) * nc, *lo = out + (r0 + tid) * nc;
             float s = 0.f;
             for (int q = 0; q < nc; ++q) s += go[q];
             for (int q = 0; q < nc; ++q) s_dl[tid * nc + q] = go[q] - expf(lo[q]) * s;
+        }
+        if (tid < nr && labels != nullptr) {
+            // the same with d_out = d(mean cross-entropy)/d(out) formed in place: d_loss / G * (softmax(out) - onehot)
+            const float *lo = out + (r0 + tid) * nc;
+            const float lse = row_lse(lo, nc);
+            const float scale = d_loss[0] / (float)dm.g;
+            const long long cls = labels[r0 + tid];
+            float s = 0.f;
+            for (int q = 0; q < nc; ++q) s += scale * (expf(lo[q] - lse) - (q == cls ? 1.f : 0.f));
+            for (int q = 0; q < nc; ++q) {
+                const float go = scale * (expf(lo[q] - lse) - (q == cls ? 1.f : 0.f));
+                s_dl[tid * nc + q] = go - expf(lo[q]) * s;
+            }
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -524,6 +569,20 @@ head_bwd_tile_kernel(const float *__restrict__ k, HeadDims dm, const float *__re
     float *dst = partials + (size_t)blockIdx.x * nv;
     for (int e = tid; e < nv; e += kBlock) dst[e] = s_g[e];
     HEAD_STAMP_AT(12);
+    if (loss_out != nullptr && blockIdx.x == 0 && tid < 64) {
+        // mean loss from the forward launch's per-block sums: lane l adds blocks l, l + 64, ... in order (at most
+        // kMaxBlocks = 256: four loads in flight), then a butterfly whose operand pairs are fixed
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int b = tid + 64 * u;
+            v[u] = loss_partials[b < n_loss_partials ? b : n_loss_partials - 1];
+            if (b >= n_loss_partials) v[u] = 0.f;
+        }
+        float acc = ((v[0] + v[1]) + v[2]) + v[3];
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (tid == 0) loss_out[0] = acc / (float)dm.g;
+    }
 }
 
 // partials[b][e] added over b = lane8, lane8 + 8, ... in that order, eight loads in flight at a time
@@ -610,14 +669,6 @@ head_bwd_finish_kernel(const float *__restrict__ k, HeadDims dm, const float *__
 // ---------------------------------------------------------------------------------------------------
 constexpr int kCeBlock = 1024;
 
-__device__ inline float row_lse(const float *__restrict__ x, int nc) {
-    float mx = x[0];
-    for (int q = 1; q < nc; ++q) mx = fmaxf(mx, x[q]);
-    float se = 0.f;
-    for (int q = 0; q < nc; ++q) se += expf(x[q] - mx);
-    return mx + logf(se);
-}
-
 __global__ void __launch_bounds__(kCeBlock)
 cross_entropy_forward_kernel(const float *__restrict__ x, const long long *__restrict__ y, long long g, int nc,
                              float *__restrict__ loss) {
@@ -693,11 +744,30 @@ int64_t rwk_head_stats_size(int64_t g, int64_t c) { return g >= 1 ? (int64_t)hea
 
 int64_t rwk_head_grad_size(int64_t c, int64_t p, int64_t nc) { return head_nv((int)c, (int)p, (int)nc); }
 
+int rwk_head_forward_loss(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
+                          const float *bn_b, float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                          float momentum, float eps, int training, float *stats, const float *w1, const float *b1,
+                          const float *w2, const float *b2, float drop_p, uint64_t *rng_state, uint64_t *rng_used,
+                          float *mean_out, float *invstd_out, float *h1d_out, float *out, const int64_t *labels,
+                          float *loss_partials, rwk_stream_t stream_);
+
 int rwk_head_forward(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
                      const float *bn_b, float *running_mean, float *running_var, int64_t *num_batches_tracked,
                      float momentum, float eps, int training, float *stats, const float *w1, const float *b1,
                      const float *w2, const float *b2, float drop_p, uint64_t *rng_state, uint64_t *rng_used,
                      float *mean_out, float *invstd_out, float *h1d_out, float *out, rwk_stream_t stream_) {
+    return rwk_head_forward_loss(k, g, c, p, nc, bn_w, bn_b, running_mean, running_var, num_batches_tracked, momentum,
+                                 eps, training, stats, w1, b1, w2, b2, drop_p, rng_state, rng_used, mean_out,
+                                 invstd_out, h1d_out, out, nullptr, nullptr, stream_);
+}
+
+int rwk_head_forward_loss(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
+                          const float *bn_b, float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                          float momentum, float eps, int training, float *stats, const float *w1, const float *b1,
+                          const float *w2, const float *b2, float drop_p, uint64_t *rng_state, uint64_t *rng_used,
+                          float *mean_out, float *invstd_out, float *h1d_out, float *out, const int64_t *labels,
+                          float *loss_partials, rwk_stream_t stream_) {
+    if ((labels == nullptr) != (loss_partials == nullptr)) return RWK_E_NULL;
     RWK_REQUIRE_PTR(k);
     RWK_REQUIRE_PTR(bn_w);
     RWK_REQUIRE_PTR(bn_b);
@@ -734,15 +804,39 @@ int rwk_head_forward(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc
     if (rc != RWK_OK) return rc;
     hipLaunchKernelGGL(head_apply_kernel, dim3(blocks), dim3(kBlock), lds, stream, k, dm, bn_w, bn_b, running_mean,
                        running_var, (long long *)num_batches_tracked, momentum, eps, training, stats, blocks, w1, b1,
-                       w2, b2, drop_p, (const unsigned long long *)rng_used, mean_out, invstd_out, h1d_out, out);
+                       w2, b2, drop_p, (const unsigned long long *)rng_used, mean_out, invstd_out, h1d_out, out,
+                       (const long long *)labels, loss_partials);
     RWK_LAUNCH_CHECK();
     return RWK_OK;
 }
+
+int rwk_head_backward_loss(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
+                           const float *bn_b, const float *mean, const float *invstd, int training, const float *w1,
+                           const float *w2, const float *h1d, const float *out, const float *d_out, float drop_p,
+                           float *dy, float *partials, float *grads, float *d_k, const int64_t *labels,
+                           const float *d_loss, const float *loss_partials, float *loss, rwk_stream_t stream_);
 
 int rwk_head_backward(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
                       const float *bn_b, const float *mean, const float *invstd, int training, const float *w1,
                       const float *w2, const float *h1d, const float *out, const float *d_out, float drop_p,
                       float *dy, float *partials, float *grads, float *d_k, rwk_stream_t stream_) {
+    RWK_REQUIRE_PTR(d_out);
+    return rwk_head_backward_loss(k, g, c, p, nc, bn_w, bn_b, mean, invstd, training, w1, w2, h1d, out, d_out, drop_p,
+                                  dy, partials, grads, d_k, nullptr, nullptr, nullptr, nullptr, stream_);
+}
+
+int rwk_head_backward_loss(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
+                           const float *bn_b, const float *mean, const float *invstd, int training, const float *w1,
+                           const float *w2, const float *h1d, const float *out, const float *d_out, float drop_p,
+                           float *dy, float *partials, float *grads, float *d_k, const int64_t *labels,
+                           const float *d_loss, const float *loss_partials, float *loss, rwk_stream_t stream_) {
+    if (labels != nullptr) {
+        RWK_REQUIRE_PTR(d_loss);
+        if ((loss == nullptr) != (loss_partials == nullptr)) return RWK_E_NULL;
+    } else {
+        RWK_REQUIRE_PTR(d_out);
+        if (loss != nullptr || loss_partials != nullptr) return RWK_E_NULL;
+    }
     RWK_REQUIRE_PTR(k);
     RWK_REQUIRE_PTR(bn_w);
     RWK_REQUIRE_PTR(bn_b);
@@ -752,7 +846,6 @@ int rwk_head_backward(const float *k, int64_t g, int64_t c, int64_t p, int64_t n
     RWK_REQUIRE_PTR(w2);
     RWK_REQUIRE_PTR(h1d);
     RWK_REQUIRE_PTR(out);
-    RWK_REQUIRE_PTR(d_out);
     RWK_REQUIRE_PTR(dy);
     RWK_REQUIRE_PTR(partials);
     RWK_REQUIRE_PTR(grads);
@@ -766,7 +859,8 @@ int rwk_head_backward(const float *k, int64_t g, int64_t c, int64_t p, int64_t n
     const int rc = allow_lds(head_bwd_tile_kernel, lds);
     if (rc != RWK_OK) return rc;
     hipLaunchKernelGGL(head_bwd_tile_kernel, dim3(blocks), dim3(kBlock), lds, stream, k, dm, bn_w, bn_b, mean, invstd,
-                       w1, w2, h1d, out, d_out, keep_scale, dy, partials);
+                       w1, w2, h1d, out, d_out, keep_scale, dy, partials, (const long long *)labels, d_loss,
+                       loss_partials, blocks, loss);
     RWK_LAUNCH_CHECK();
     hipLaunchKernelGGL(head_bwd_finish_kernel, dim3(blocks), dim3(kBlock), 0, stream, k, dm, bn_w, mean, invstd, dy,
                        partials, blocks, training, grads, d_k);

@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["head_supported", "fused_head"]
+__all__ = ["head_supported", "fused_head", "fused_head_loss"]
 
 
 def head_supported(n_graphs: int, n_features: int, penultimate_dim: int, n_classes: int) -> bool:
@@ -87,6 +87,103 @@ class _FusedHead(torch.autograd.Function):
         d_bn_w = grads[o:o + c]; o += c
         d_bn_b = grads[o:o + c]
         return (d_k, d_bn_w, d_bn_b, d_w1, d_b1, d_w2, d_b2) + (None,) * 8
+
+
+class _FusedHeadLoss(torch.autograd.Function):
+    """The head and ``F.cross_entropy(out, labels)`` (``rwgnn2/main.py:84-85``) as one autograd node: returns
+    ``(out, loss)``; only ``loss`` carries a gradient.  The forward launch leaves per-workgroup loss sums, the
+    backward launch forms the loss gradient in place and finishes the loss value, so the two cross-entropy
+    launches disappear.  When no backward pass will follow, the loss is computed at once by its own kernel."""
+
+    @staticmethod
+    def forward(ctx, k, labels, bn_w, bn_b, w1, b1, w2, b2, running_mean, running_var, num_batches_tracked, momentum,
+                eps, training, drop_p, rng_state, grad_mode):
+        lib = _lib.load()
+        if not k.is_cuda:
+            raise RuntimeError("gnn_amd runs on HIP devices only (no CPU fallback)")
+        g, c = k.shape
+        p, nc = w1.shape[0], w2.shape[0]
+        dev = k.device
+        training = bool(training)
+        if training and g < 2:
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s"
+                             % (tuple(k.shape),))
+        if labels.dtype != torch.int64 or labels.shape != (g,) or labels.device != dev:
+            raise ValueError("labels must be an int64 tensor of one class index per graph on the device of k")
+        drop = float(drop_p) if (training and drop_p and rng_state is not None) else 0.0
+        # grad_mode: the caller's torch.is_grad_enabled() (inside forward() it is always off, and
+        # needs_input_grad reports requires_grad of the inputs whatever the mode)
+        needs_grad = bool(grad_mode) and any(ctx.needs_input_grad[:1] + ctx.needs_input_grad[2:8])
+        with _lib.device_guard(dev):
+            stream = _lib.current_stream(dev)
+            kc = k.detach().contiguous()
+            yc = labels.contiguous()
+            bn_wc, bn_bc, w1c, b1c, w2c, b2c = [t.detach().contiguous() for t in (bn_w, bn_b, w1, b1, w2, b2)]
+            out = torch.empty((g, nc), dtype=torch.float32, device=dev)
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            stats = torch.empty(lib.rwk_head_stats_size(g, c), dtype=torch.float32, device=dev) if training else None
+            keep = training or needs_grad
+            mean = torch.empty(c, dtype=torch.float32, device=dev) if keep else None
+            invstd = torch.empty(c, dtype=torch.float32, device=dev) if keep else None
+            h1d = torch.empty((g, p), dtype=torch.float32, device=dev) if needs_grad else None
+            rng_used = torch.empty(2, dtype=torch.int64, device=dev) if drop else None
+            loss_partials = torch.empty(lib.rwk_head_n_blocks(g), dtype=torch.float32, device=dev) if needs_grad \
+                else None
+            _lib.check(lib.rwk_head_forward_loss(
+                kc.data_ptr(), g, c, p, nc, bn_wc.data_ptr(), bn_bc.data_ptr(), running_mean.data_ptr(),
+                running_var.data_ptr(), _lib.ptr(num_batches_tracked), float(momentum), float(eps), int(training),
+                _lib.ptr(stats), w1c.data_ptr(), b1c.data_ptr(), w2c.data_ptr(), b2c.data_ptr(), drop,
+                _lib.ptr(rng_state) if drop else None, _lib.ptr(rng_used), _lib.ptr(mean), _lib.ptr(invstd),
+                _lib.ptr(h1d), out.data_ptr(), yc.data_ptr() if needs_grad else None, _lib.ptr(loss_partials),
+                stream), "rwk_head_forward_loss")
+            if not needs_grad:
+                _lib.check(lib.rwk_cross_entropy_forward(out.data_ptr(), yc.data_ptr(), g, nc, loss.data_ptr(),
+                                                         stream), "rwk_cross_entropy_forward")
+        ctx.cfg = (training, drop)
+        ctx.save_for_backward(kc, yc, bn_wc, bn_bc, w1c, w2c, mean, invstd, h1d, out, loss_partials, loss)
+        ctx.mark_non_differentiable(out)
+        return out, loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, _d_out, d_loss):
+        lib = _lib.load()
+        kc, yc, bn_wc, bn_bc, w1c, w2c, mean, invstd, h1d, out, loss_partials, loss = ctx.saved_tensors
+        training, drop = ctx.cfg
+        g, c = kc.shape
+        p, nc = w1c.shape[0], w2c.shape[0]
+        dev = kc.device
+        with _lib.device_guard(dev):
+            stream = _lib.current_stream(dev)
+            d_loss = d_loss.contiguous().float()
+            nv = lib.rwk_head_grad_size(c, p, nc)
+            blocks = lib.rwk_head_n_blocks(g)
+            dy = torch.empty((g, c), dtype=torch.float32, device=dev)
+            partials = torch.empty((blocks, nv), dtype=torch.float32, device=dev)
+            grads = torch.empty(nv, dtype=torch.float32, device=dev)
+            d_k = torch.empty((g, c), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+            _lib.check(lib.rwk_head_backward_loss(
+                kc.data_ptr(), g, c, p, nc, bn_wc.data_ptr(), bn_bc.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                int(training), w1c.data_ptr(), w2c.data_ptr(), h1d.data_ptr(), out.data_ptr(), None, drop,
+                dy.data_ptr(), partials.data_ptr(), grads.data_ptr(), _lib.ptr(d_k), yc.data_ptr(),
+                d_loss.data_ptr(), loss_partials.data_ptr(), loss.data_ptr(), stream), "rwk_head_backward_loss")
+        o = 0
+        d_w2 = grads[o:o + nc * p].view(nc, p); o += nc * p
+        d_b2 = grads[o:o + nc]; o += nc
+        d_w1 = grads[o:o + p * c].view(p, c); o += p * c
+        d_b1 = grads[o:o + p]; o += p
+        d_bn_w = grads[o:o + c]; o += c
+        d_bn_b = grads[o:o + c]
+        return (d_k, None, d_bn_w, d_bn_b, d_w1, d_b1, d_w2, d_b2) + (None,) * 9
+
+
+def fused_head_loss(k, labels, bn, fc1, fc2, drop_p: float, training: bool, rng_state=None):
+    """``out = fused_head(...)`` and ``loss = F.cross_entropy(out, labels)`` in the head's own launches; returns
+    ``(out, loss)`` with ``out`` detached.  With gradients enabled the value of ``loss`` is complete once
+    ``loss.backward()`` has run (the backward launch finishes the sum): read it after the step."""
+    return _FusedHeadLoss.apply(k, labels, bn.weight, bn.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias,
+                                bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps,
+                                training, drop_p, rng_state, torch.is_grad_enabled())
 
 
 def fused_head(k, bn, fc1, fc2, drop_p: float, training: bool, rng_state=None):

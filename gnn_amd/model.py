@@ -15,7 +15,8 @@ import torch.nn.functional as F
 from torch.nn.parameter import Parameter
 
 from .function import FUSED_PROJECTION_MAX_INPUT_DIM, rw_kernel_layer, rw_kernel_layer_projected
-from .head import fused_head, head_supported
+from .head import fused_head, fused_head_loss, head_supported
+from .losses import cross_entropy
 from .structure import get_structure
 
 __all__ = ["RW_NN"]
@@ -70,6 +71,9 @@ class RW_NN(nn.Module):
             k = k + 0.0 * (pre.sum() + self.features_hidden.sum() + self.adj_hidden.sum())
         else:
             k = self._rw(features, structure, drop)
+        return self._head(k, drop)
+
+    def _head(self, k, drop):
         if self._use_fused_head(k, drop):
             if drop > 0.0 and not self._rng_seeded:
                 self._seed_from_torch()
@@ -80,6 +84,26 @@ class RW_NN(nn.Module):
         out = self.dropout(out)
         out = self.fc2(out)
         return F.log_softmax(out, dim=1)
+
+    def forward_with_loss(self, adj, features, graph_indicator, y):
+        """``output = self(adj, features, graph_indicator); loss = F.cross_entropy(output, y)`` of the training loop
+        (``rwgnn2/main.py:84-85``), returned as ``(output, loss)``.  With the fused head and gradients enabled the
+        loss rides in the head's launches (:func:`gnn_amd.head.fused_head_loss`): its value is complete after
+        ``loss.backward()``, and ``output`` is detached."""
+        structure = get_structure(adj, graph_indicator)
+        p = float(self.dropout.p)
+        drop = p if self.training else 0.0
+        if drop < 1.0 and torch.is_grad_enabled():
+            k = self._rw(features, structure, drop)
+            if self._use_fused_head(k, drop) and y.dtype == torch.int64 and y.dim() == 1:
+                if drop > 0.0 and not self._rng_seeded:
+                    self._seed_from_torch()
+                return fused_head_loss(k, y, self.bn, self.fc1, self.fc2, drop, self.training,
+                                       self._rng_state if drop > 0.0 else None)
+            out = self._head(k, drop)
+        else:
+            out = self.forward(adj, features, graph_indicator)
+        return out, cross_entropy(out, y)
 
     def _use_fused_head(self, k, drop):
         bn = self.bn

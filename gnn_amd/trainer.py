@@ -26,7 +26,7 @@ class Trainer:
 
     ``world`` > 1: the flat gradient bucket is all-reduced (mean) over the default process group between the
     backward and the optimiser step.  ``fused_loss``: ``gnn_amd.losses.cross_entropy`` (same value and gradient
-    as ``F.cross_entropy``, two launches instead of torch's eight).  ``optimizer``: "flat" (``gnn_amd.optim.FlatAdam``, same arithmetic as
+    as ``F.cross_entropy``, two launches instead of torch's eight; for ``RW_NN`` inside the head's own launches).  ``optimizer``: "flat" (``gnn_amd.optim.FlatAdam``, same arithmetic as
     ``torch.optim.Adam``, one launch) or "torch" (``torch.optim.Adam(capturable=True)``).
     """
 
@@ -47,6 +47,9 @@ class Trainer:
             self.opt = torch.optim.Adam(model.parameters(), lr=lr, capturable=True, foreach=True)
         # F.cross_entropy(output, y) of main.py:85, one launch each way (gnn_amd.losses) or torch's own kernels
         self.loss_fn = cross_entropy if fused_loss else F.cross_entropy
+        # RW_NN with the fused loss: the cross-entropy rides in the head's launches (model.forward_with_loss); the
+        # loss value is then complete at the end of the step, which is when step_*() callers read it
+        self.loss_in_head = fused_loss and forward_fn is None and hasattr(model, "forward_with_loss")
         # one process, flat optimiser: the gradient gather rides in the Adam launch
         self.fused_gather = world == 1 and optimizer == "flat"
         # gloo's all-reduce of a device tensor was seen to hang when the device still has queued work (two ranks on
@@ -63,8 +66,11 @@ class Trainer:
 
     def fwd_bwd(self):
         self.bucket.release()            # optimizer.zero_grad(set_to_none=True)
-        out = self.forward_fn()
-        self.loss = self.loss_fn(out, self.y)
+        if self.loss_in_head:
+            _, self.loss = self.model.forward_with_loss(self.adj, self.feats, self.gi, self.y)
+        else:
+            out = self.forward_fn()
+            self.loss = self.loss_fn(out, self.y)
         self.loss.backward(self._one)
         if not self.fused_gather:
             self.bucket.gather()         # per-parameter gradients -> the flat bucket, one launch

@@ -264,6 +264,29 @@ int rwk_head_backward(const float *k, int64_t g, int64_t c, int64_t p, int64_t n
                       const float *d_out, float drop_p, float *dy, float *partials, float *grads,
                       float *d_k, rwk_stream_t stream);
 
+/* The head together with the mean cross-entropy that rwgnn2/main.py:85 applies to its output (output =
+ * model(...); loss = F.cross_entropy(output, y)), without the two cross-entropy launches:
+ * rwk_head_forward_loss also writes, per workgroup, the sum of -log p(label) over its rows to loss_partials
+ * (rwk_head_n_blocks(g) floats); rwk_head_backward_loss forms d_out = d_loss[0] / g * (softmax(out) -
+ * onehot(labels)) in place (d_out is ignored and may be NULL when labels is given) and, when loss is
+ * non-null, writes the mean loss (the partials added in a fixed order, divided by g) to loss[0].  The loss
+ * value is therefore complete after the backward call; a caller that needs it without a backward pass calls
+ * rwk_cross_entropy_forward on out.  labels == NULL (with loss_partials, d_loss, loss NULL): exactly
+ * rwk_head_forward / rwk_head_backward. */
+int rwk_head_forward_loss(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
+                          const float *bn_b, float *running_mean, float *running_var,
+                          int64_t *num_batches_tracked, float momentum, float eps, int training, float *stats,
+                          const float *w1, const float *b1, const float *w2, const float *b2, float drop_p,
+                          uint64_t *rng_state, uint64_t *rng_used, float *mean_out, float *invstd_out,
+                          float *h1d_out, float *out, const int64_t *labels, float *loss_partials,
+                          rwk_stream_t stream);
+int rwk_head_backward_loss(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
+                           const float *bn_b, const float *mean, const float *invstd, int training,
+                           const float *w1, const float *w2, const float *h1d, const float *out,
+                           const float *d_out, float drop_p, float *dy, float *partials, float *grads,
+                           float *d_k, const int64_t *labels, const float *d_loss, const float *loss_partials,
+                           float *loss, rwk_stream_t stream);
+
 /* Mean cross-entropy of (g, nc) scores against int64 labels in [0, nc): F.cross_entropy with its
  * default arguments, as rwgnn2/main.py:85,92 applies it to the model's output.  loss: device
  * float[1].  Backward: d_scores = d_loss[0] / g * (softmax(scores) - onehot(labels)).

@@ -202,3 +202,88 @@ def test_model_head_switch(dev):
     for n in res[True][1]:
         assert rel(res[True][1][n], res[False][1][n]) < 5e-3, n
     assert rel(res[True][2], res[False][2]) < 1e-4
+
+
+@pytest.mark.parametrize("g,c,p,nc", [(64, 32, 32, 2), (33, 32, 32, 2), (1000, 128, 32, 7), (9000, 48, 20, 3),
+                                      (2, 16, 8, 2), (1024, 32, 32, 2), (4096, 128, 32, 2)])
+def test_head_with_loss_equals_head_then_cross_entropy(dev, g, c, p, nc):
+    """fused_head_loss (the cross-entropy inside the head's launches) against fused_head followed by
+    gnn_amd.losses.cross_entropy: same log-probabilities bit for bit, the same gradients (the loss gradient is formed
+    by the same expressions, in place: equal bits expected, 1e-6 allowed), the loss value to 1e-6 (its rows are added
+    in another order), and against the float64 torch reference at the tolerances of the separate path."""
+    from gnn_amd.head import fused_head, fused_head_loss
+    from gnn_amd.losses import cross_entropy
+    m, m64, k, y = make_case(g, c, p, nc, True)
+    k64 = k.double().requires_grad_(True)
+    out_ref, loss_ref = reference(m64, k64, y, True)
+    loss_ref.backward()
+
+    import copy
+    ma = m.to(dev).train()
+    mb = copy.deepcopy(ma)
+    yd = y.to(dev)
+    ka = k.to(dev).requires_grad_(True)
+    out_a = fused_head(ka, ma.bn, ma.fc1, ma.fc2, 0.0, True)
+    loss_a = cross_entropy(out_a, yd)
+    loss_a.backward()
+    kb = k.to(dev).requires_grad_(True)
+    out_b, loss_b = fused_head_loss(kb, yd, mb.bn, mb.fc1, mb.fc2, 0.0, True)
+    assert not out_b.requires_grad
+    loss_b.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(out_a.detach(), out_b)
+    assert abs(float(loss_a) - float(loss_b)) < 1e-6 * abs(float(loss_a))
+    assert abs(float(loss_b) - float(loss_ref)) < TOL * abs(float(loss_ref))
+    assert rel(kb.grad, ka.grad) < 1e-6
+    assert rel(kb.grad, k64.grad) < 5e-5
+    for (name, pa), (_, pb), (_, ref) in zip(ma.named_parameters(), mb.named_parameters(), m64.named_parameters()):
+        assert rel(pb.grad, pa.grad) < 1e-6, name
+        assert rel(pb.grad, ref.grad) < 1e-4, name
+    assert torch.equal(ma.bn.running_mean, mb.bn.running_mean)
+    assert torch.equal(ma.bn.running_var, mb.bn.running_var)
+
+
+def test_head_with_loss_scaled_gradient_and_no_grad(dev):
+    """d_loss other than one scales every gradient; without gradients the loss is complete at once."""
+    from gnn_amd.head import fused_head_loss
+    g, c, p, nc = 300, 32, 32, 3
+    m, m64, k, y = make_case(g, c, p, nc, True)
+    md = m.to(dev).train()
+    yd = y.to(dev)
+    k1 = k.to(dev).requires_grad_(True)
+    _, l1 = fused_head_loss(k1, yd, md.bn, md.fc1, md.fc2, 0.0, True)
+    l1.backward()
+    g1 = k1.grad.clone()
+    k2 = k.to(dev).requires_grad_(True)
+    _, l2 = fused_head_loss(k2, yd, md.bn, md.fc1, md.fc2, 0.0, True)
+    (l2 * 3.0).backward()
+    assert rel(k2.grad, 3.0 * g1) < 1e-6
+    md.eval()
+    with torch.no_grad():
+        out, loss = fused_head_loss(k.to(dev), yd, md.bn, md.fc1, md.fc2, 0.0, False)
+    want = F.cross_entropy(out.double(), yd)
+    assert abs(float(loss) - float(want)) < 1e-6 * abs(float(want))
+
+
+def test_model_forward_with_loss(dev):
+    """RW_NN.forward_with_loss against forward + F.cross_entropy on the same dropout draws."""
+    from gnn_amd import RW_NN
+    from gnn_amd.synth import random_batch
+    b = random_batch(48, 10, 30, 2.5, seed=5)
+    adj, feats, gi, y = b.to_torch(dev)
+    torch.manual_seed(0)
+    ma = RW_NN(1, 2, 16, 5, 4, 32, False, 2, 0.2, dev).to(dev).train()
+    import copy
+    mb = copy.deepcopy(ma)
+    ma.seed_dropout(77)
+    mb.seed_dropout(77)
+    out_a = ma(adj, feats, gi)
+    loss_a = F.cross_entropy(out_a, y)
+    loss_a.backward()
+    out_b, loss_b = mb.forward_with_loss(adj, feats, gi, y)
+    loss_b.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(out_a.detach(), out_b)
+    assert abs(float(loss_a) - float(loss_b)) < 1e-6 * abs(float(loss_a))
+    for (name, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert rel(pb.grad, pa.grad) < 2e-5, name
