@@ -58,6 +58,15 @@ __host__ __device__ inline int head_blocks(long long g) {
     return (int)(t < kMaxBlocks ? t : kMaxBlocks);
 }
 
+// Workgroups of the statistics launch.  Every workgroup of the apply launch merges all of their partials for
+// every column (a round trip to L2 per 64 of them and per 32 columns), so there are fewer of them than row
+// tiles: the statistics pass itself only reads K once more however it is cut.
+constexpr int kMaxStatsBlocks = 64;
+__host__ __device__ inline int head_stats_blocks(long long g) {
+    const int b = head_blocks(g);
+    return b < kMaxStatsBlocks ? b : kMaxStatsBlocks;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // batch statistics: partials[b] = {count, mean[C], M2[C]} over the rows of block b's tiles
 // ---------------------------------------------------------------------------------------------------
@@ -794,7 +803,7 @@ int rwk_head_forward_loss(const float *k, int64_t g, int64_t c, int64_t p, int64
     const int blocks = head_blocks(g);
     const HeadDims dm{(long long)g, (int)c, (int)p, (int)nc};
     if (training) {
-        hipLaunchKernelGGL(head_stats_kernel, dim3(blocks), dim3(kBlock), 0, stream, k, (long long)g, (int)c, stats,
+        hipLaunchKernelGGL(head_stats_kernel, dim3(head_stats_blocks(g)), dim3(kBlock), 0, stream, k, (long long)g, (int)c, stats,
                            drop ? (unsigned long long *)rng_state : nullptr,
                            drop ? (unsigned long long *)rng_used : nullptr);
         RWK_LAUNCH_CHECK();
@@ -803,7 +812,7 @@ int rwk_head_forward_loss(const float *k, int64_t g, int64_t c, int64_t p, int64
     const int rc = allow_lds(head_apply_kernel, lds);
     if (rc != RWK_OK) return rc;
     hipLaunchKernelGGL(head_apply_kernel, dim3(blocks), dim3(kBlock), lds, stream, k, dm, bn_w, bn_b, running_mean,
-                       running_var, (long long *)num_batches_tracked, momentum, eps, training, stats, blocks, w1, b1,
+                       running_var, (long long *)num_batches_tracked, momentum, eps, training, stats, head_stats_blocks(g), w1, b1,
                        w2, b2, drop_p, (const unsigned long long *)rng_used, mean_out, invstd_out, h1d_out, out,
                        (const long long *)labels, loss_partials);
     RWK_LAUNCH_CHECK();
