@@ -58,6 +58,11 @@ SIGNATURES = {
                                       _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rwk_head_backward_loss": (c_int, [_P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_float,
                                        _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "rwk_khop_count": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P]),
+    "rwk_khop_fill": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P]),
+    "rwk_segment_sum": (c_int, [_P, _P, _I64, _I64, _P, _P]),
+    "rwk_distance_bias_combine": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_float, _I64, _I64, _P, _P]),
+    "rwk_row_scale": (c_int, [_P, _P, _I64, _I64, _P, _P]),
     "rwk_cross_entropy_forward": (c_int, [_P, _P, _I64, _I64, _P, _P]),
     "rwk_cross_entropy_backward": (c_int, [_P, _P, _I64, _I64, _P, _P, _P]),
     "rwk_project_forward": (c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),

@@ -387,6 +387,41 @@ int rwk_adam_step_chunks(float *param, const float *const *srcs, const int64_t *
 int rwk_dropout_mask(const uint64_t *rng, int64_t n, int64_t h, int64_t s, int64_t max_step,
                      float drop_p, uint8_t *keep, rwk_stream_t stream);
 
+/* ---- distance-biased transition operator (rwgnn2/rwgnn_dis_bias6.py:109-128 and :222-250) --------------------
+ * P = (1 - c) * rownorm(W) + c / n_g per graph, W[i][j] = f(hop distance) off the diagonal, every pair further
+ * apart than max_distance at max_distance + 1.  W = w_far * (1 1^T - I) + Y with Y sparse over the
+ * max_distance-hop neighbourhoods; these entry points build Y's structure and apply the dense remainder, Y x is
+ * rwk_spmm_csr on (row_start, out_col, values).
+ *
+ * rwk_khop_count / rwk_khop_fill: breadth-first search from every node inside its own graph (gid: graph of each
+ * node, seg_ptr: first node of each graph; nodes of a graph contiguous; max_graph_nodes: size of the largest
+ * graph, at most 409,600).  count: row_count[i] = nodes within 1..max_distance hops of i, level_count[i *
+ * max_distance + d - 1] = nodes at exactly d hops.  fill: with row_start = exclusive prefix sum of row_count
+ * (n + 1 entries), writes each row's (node, distance) pairs ordered by distance, then node.  The reference computes
+ * the same distances from dense powers of the adjacency matrix (:109-128) or scipy's dijkstra with a limit
+ * (:130-154). */
+int rwk_khop_count(const int32_t *crow, const int32_t *col, const int32_t *gid, const int32_t *seg_ptr, int64_t n,
+                   int64_t max_graph_nodes, int64_t max_distance, int32_t *row_count, int32_t *level_count,
+                   rwk_stream_t stream);
+int rwk_khop_fill(const int32_t *crow, const int32_t *col, const int32_t *gid, const int32_t *seg_ptr, int64_t n,
+                  int64_t max_graph_nodes, int64_t max_distance, const int32_t *row_start, int32_t *out_col,
+                  int32_t *out_dist, rwk_stream_t stream);
+
+/* out[g][c] = sum over the rows of graph g of x[r][c] (fixed order); d <= 256. */
+int rwk_segment_sum(const float *x, const int32_t *seg_ptr, int64_t n_graphs, int64_t d, float *out,
+                    rwk_stream_t stream);
+
+/* out[i][c] = a_i * (w_far * (s1[g][c] - x[i][c]) + y[i][c]) + graph_scale[g] * s2[g][c] with g = gid[i] and
+ * a_i = row_scale[i] (1 when row_scale is NULL).  Forward of P x (:244): x, y = Y x, s1 = s2 = per-graph sums of
+ * x, row_scale = (1 - c) / rowsum, graph_scale = c / n_g.  Backward (P^T g): x = v = row_scale * g, y = Y v,
+ * s1 = sums of v, s2 = sums of g, row_scale NULL. */
+int rwk_distance_bias_combine(const float *x, const float *y, const float *s1, const float *s2, const int32_t *gid,
+                              const float *row_scale, const float *graph_scale, float w_far, int64_t n, int64_t d,
+                              float *out, rwk_stream_t stream);
+
+/* out[i][c] = x[i][c] * scale[i] */
+int rwk_row_scale(const float *x, const float *scale, int64_t n, int64_t d, float *out, rwk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

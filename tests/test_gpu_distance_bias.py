@@ -1,0 +1,120 @@
+"""Distance-biased transition operator (gnn_amd.distance_bias) against the dense CPU restatement
+(oracle/distance_bias_oracle.py) of rwgnn2/rwgnn_dis_bias6.py:109-128, :222-250.  PARITY UNPINNED: the reference
+module cannot be imported (torch_geometric) and holds no fixture for these matrices."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle import distance_bias_oracle as oracle  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    return torch.device("cuda:0")
+
+
+def dense_adj(b):
+    a = np.zeros((b.n_nodes, b.n_nodes), dtype=np.float32)
+    a[b.indices[0], b.indices[1]] = b.values
+    return a
+
+
+def batches():
+    from gnn_amd.synth import powerlaw_batch, random_batch
+    return {
+        "sparse": random_batch(12, 5, 40, 2.2, seed=1),          # several components per graph: many far pairs
+        "denser": random_batch(6, 20, 70, 5.0, seed=2),
+        "hubs": powerlaw_batch(5, 30, 90, 2.1, seed=3),
+        "one_graph": random_batch(1, 300, 300, 3.0, seed=4),      # bitmap of ten words, rows of hundreds of pairs
+        "tiny": random_batch(7, 1, 3, 1.0, seed=5),               # graphs of one to three nodes
+    }
+
+
+@pytest.mark.parametrize("name", ["sparse", "denser", "hubs", "one_graph", "tiny"])
+@pytest.mark.parametrize("max_distance", [1, 3, 4])
+def test_hop_structure_is_exact(dev, name, max_distance):
+    """Integer work, bit-exact: stored pairs = exactly the pairs at 1..max_distance hops with their distance, rows
+    ordered by (distance, node), per-level counts."""
+    from gnn_amd.distance_bias import distance_bias_structure
+    b = batches()[name]
+    adj, feats, gi, y = b.to_torch(dev)
+    st = distance_bias_structure(adj, gi, max_distance=max_distance)
+    a = dense_adj(b)
+    _, dists = oracle.apply_batch(a, b.sizes, np.zeros((b.n_nodes, 1)), max_distance=max_distance)
+    start = st.row_start.cpu().numpy()
+    col = st.col.cpu().numpy()
+    dist = st.dist.cpu().numpy()
+    levels = st.level_count.cpu().numpy()
+    lo = 0
+    for ng, dm in zip(b.sizes, dists):
+        for i in range(ng):
+            want = [(int(dm[i, j]), lo + j) for j in range(ng) if 1 <= dm[i, j] <= max_distance]
+            want.sort()
+            s, e = start[lo + i], start[lo + i + 1]
+            got = list(zip(dist[s:e].tolist(), col[s:e].tolist()))
+            assert got == want, (name, lo + i)
+            for d in range(1, max_distance + 1):
+                assert levels[lo + i, d - 1] == sum(1 for w in want if w[0] == d)
+        lo += int(ng)
+    assert start[-1] == col.size
+
+
+@pytest.mark.parametrize("name", ["sparse", "denser", "hubs", "one_graph", "tiny"])
+@pytest.mark.parametrize("walk_type,alpha,c,max_distance", [("exp", 1.0, 0.1, 3), ("levy", 1.5, 0.3, 4),
+                                                            ("exp", 0.5, 0.0, 2)])
+def test_operator_forward_backward(dev, name, walk_type, alpha, c, max_distance):
+    """P x and P^T g against the dense float64 matrices; fp32 sums over up to 300 terms: rtol 1e-5 of the largest
+    magnitude."""
+    from gnn_amd.distance_bias import distance_bias_propagate, distance_bias_structure
+    b = batches()[name]
+    adj, feats, gi, y = b.to_torch(dev)
+    rng = np.random.default_rng(7)
+    d = 5
+    x = rng.normal(size=(b.n_nodes, d)).astype(np.float32)
+    g = rng.normal(size=(b.n_nodes, d)).astype(np.float32)
+    a = dense_adj(b)
+    want, dists = oracle.apply_batch(a, b.sizes, x, max_distance, walk_type, alpha, c)
+    want_t = np.zeros_like(want)
+    lo = 0
+    for ng, dm in zip(b.sizes, dists):
+        p = oracle.walk_probabilities(dm, walk_type, alpha, c)
+        want_t[lo:lo + ng] = p.T @ g[lo:lo + ng].astype(np.float64)
+        lo += int(ng)
+    st = distance_bias_structure(adj, gi, max_distance, walk_type, alpha, c)
+    xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+    out = distance_bias_propagate(xd, st)
+    out.backward(torch.from_numpy(g).to(dev))
+    got, got_t = out.detach().cpu().numpy(), xd.grad.cpu().numpy()
+    assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+    assert np.abs(got_t - want_t).max() <= 1e-5 * max(1.0, np.abs(want_t).max())
+    # rows of P sum to one (graphs of more than one node): P 1 = 1
+    ones = torch.ones(b.n_nodes, 3, device=dev)
+    p1 = distance_bias_propagate(ones, st).cpu().numpy()
+    big = np.repeat(b.sizes > 1, b.sizes)
+    assert np.abs(p1[big] - 1.0).max() < 1e-5
+    # bitwise reproducible
+    assert torch.equal(distance_bias_propagate(xd.detach(), st), out.detach())
+
+
+def test_distance_bias_errors(dev):
+    from gnn_amd.distance_bias import distance_bias_propagate, distance_bias_structure
+    from gnn_amd.synth import random_batch
+    b = random_batch(3, 5, 9, 2.0, seed=9)
+    adj, feats, gi, y = b.to_torch(dev)
+    with pytest.raises(ValueError):
+        distance_bias_structure(adj, gi, max_distance=0)
+    with pytest.raises(ValueError):
+        distance_bias_structure(adj, gi, walk_type="other")
+    st = distance_bias_structure(adj, gi)
+    with pytest.raises(ValueError):
+        distance_bias_propagate(torch.zeros(b.n_nodes + 1, 4, device=dev), st)
+    with pytest.raises(RuntimeError):
+        distance_bias_propagate(torch.zeros(b.n_nodes, 4), st)

@@ -140,3 +140,26 @@ def test_rwconv_oracle_against_dense_matrix():
     dx, dw, db = R.rwconv_backward(x, ei, w, d)
     assert np.abs(dx - m.T @ (d @ w)).max() < 1e-12
     assert np.abs(dw - d.T @ (m @ x)).max() < 1e-12 and np.abs(db - d.sum(0)).max() < 1e-12
+
+
+def test_distance_bias_oracle_against_scipy_dijkstra():
+    """The oracle's hop distances (dense powers, rwgnn2/rwgnn_dis_bias6.py:109-128) equal scipy's dijkstra with a
+    limit and inf -> max_distance + 1 (:130-154), the reference's other way to the same matrix; rows of the
+    transition matrix sum to one (:239-244)."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import dijkstra
+    from oracle import distance_bias_oracle as o
+    rng = np.random.default_rng(0)
+    for n, p, md in [(30, 0.08, 3), (50, 0.05, 4), (12, 0.3, 2), (1, 0.0, 3), (40, 0.02, 3)]:
+        a = (rng.random((n, n)) < p).astype(np.float32)
+        a = np.triu(a, 1)
+        a = a + a.T
+        d = o.hop_distances(a, md)
+        ref = dijkstra(csr_matrix(a), directed=False, limit=md, unweighted=True)
+        ref[ref == np.inf] = md + 1
+        assert np.array_equal(d, ref.astype(np.float32)), (n, md)
+        for walk_type, alpha, c in [("exp", 1.0, 0.1), ("levy", 2.0, 0.25)]:
+            pm = o.walk_probabilities(d, walk_type, alpha, c)
+            if n > 1:
+                assert np.allclose(pm.sum(1), 1.0)
+            assert np.allclose(np.diag(pm), c / n)
