@@ -21,7 +21,7 @@ import math
 import torch
 
 from . import _lib
-from .structure import get_structure
+from .structure import get_structure, spmm_schedule, use_tile_kernel
 
 __all__ = ["DistanceBiasStructure", "distance_bias_structure", "distance_bias_propagate"]
 
@@ -31,13 +31,18 @@ class DistanceBiasStructure:
     the hop distance of every stored pair), ``row_scale`` (N), ``graph_scale`` (G), ``w_far``."""
 
     __slots__ = ("base", "n", "max_distance", "row_start", "col", "dist", "val", "level_count", "row_scale",
-                 "graph_scale", "w_far", "weights")
+                 "graph_scale", "w_far", "weights", "max_degree", "row_lanes", "long_threshold", "long_rows")
 
     def spmm(self, x: torch.Tensor, y: torch.Tensor):
         lib = _lib.load()
-        # tile kernel (row_lanes = 0): any row length, no separate list of long rows
+        # the launch shape follows the same degree rule as the adjacency product: the tile kernel (row_lanes = 0)
+        # for short rows, the packed kernel with a wavefront per very long row once rows hold 32 pairs on average
+        nnz = self.col.numel()
+        tile = use_tile_kernel(self.n, nnz, self.max_degree, x.shape[1])
+        n_long = 0 if (tile or self.long_rows is None) else self.long_rows.numel()
         _lib.check(lib.rwk_spmm_csr(self.row_start.data_ptr(), _lib.ptr(self.col), _lib.ptr(self.val), self.n,
-                                    x.shape[1], x.data_ptr(), y.data_ptr(), 0, 0, None, 0, 0,
+                                    x.shape[1], x.data_ptr(), y.data_ptr(), 0, 0 if tile else self.row_lanes,
+                                    _lib.ptr(self.long_rows) if n_long else None, n_long, self.long_threshold,
                                     _lib.current_stream(x.device)), "rwk_spmm_csr")
 
 
@@ -81,6 +86,10 @@ def distance_bias_structure(adj: torch.Tensor, graph_indicator: torch.Tensor, ma
         if nnz >= 2 ** 31:
             raise NotImplementedError("more than 2^31 node pairs within max_distance hops")
         st.row_start = starts.to(torch.int32)
+        st.max_degree = int(row_count.max().item())
+        st.row_lanes, st.long_threshold = spmm_schedule(n, nnz, st.max_degree)
+        st.long_rows = torch.nonzero(row_count > st.long_threshold).flatten().to(torch.int32) \
+            if st.long_threshold else None
         st.col = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)[:nnz]
         st.dist = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)[:nnz]
         if nnz:
