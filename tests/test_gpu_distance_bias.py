@@ -118,3 +118,37 @@ def test_distance_bias_errors(dev):
         distance_bias_propagate(torch.zeros(b.n_nodes + 1, 4, device=dev), st)
     with pytest.raises(RuntimeError):
         distance_bias_propagate(torch.zeros(b.n_nodes, 4), st)
+
+
+def test_full_size_properties(dev):
+    """The headline batch (1024 graphs, 307 842 nodes, 17.6 M pairs within three hops), through properties that
+    need no dense matrix: rows of P sum to one; <P x, g> = <x, P^T g> (forward and backward are adjoint); stored
+    pairs are symmetric in count per distance (hop distance is symmetric); the one-hop level is the adjacency
+    matrix itself."""
+    from gnn_amd.distance_bias import distance_bias_propagate, distance_bias_structure
+    from gnn_amd.synth import config_batch
+    b = config_batch("proteins1024", 1)
+    adj, feats, gi, y = b.to_torch(dev)
+    st = distance_bias_structure(adj, gi, max_distance=3, walk_type="exp", alpha=1.0, c=0.1)
+    n = b.n_nodes
+    ones = torch.ones(n, 2, device=dev)
+    assert float((distance_bias_propagate(ones, st) - 1.0).abs().max()) < 1e-5
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    x = torch.randn(n, 4, generator=gen).to(dev).requires_grad_(True)
+    g = torch.randn(n, 4, generator=gen).to(dev)
+    out = distance_bias_propagate(x, st)
+    out.backward(g)
+    lhs = float((out.detach().double() * g.double()).sum())
+    rhs = float((x.detach().double() * x.grad.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0)
+    # integer structure: level one is A (same row pointers and columns), and each distance occurs equally often
+    # as (i, j) and (j, i)
+    lc = st.level_count.long()
+    assert torch.equal(lc[:, 0], (st.base.csr.crow[1:] - st.base.csr.crow[:-1]).long())
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), (st.row_start[1:] - st.row_start[:-1]).long())
+    for d in (1, 2, 3):
+        sel = st.dist == d
+        by_row = torch.bincount(rows[sel], minlength=n)
+        by_col = torch.bincount(st.col[sel].long(), minlength=n)
+        assert torch.equal(by_row, by_col)
+        assert torch.equal(by_row, lc[:, d - 1])
