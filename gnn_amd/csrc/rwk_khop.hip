@@ -129,8 +129,18 @@ segment_sum_kernel(const float *__restrict__ x, const int *__restrict__ seg_ptr,
     const int lo = seg_ptr[g], hi = seg_ptr[g + 1];
     const int c = tid % dpad, slot = tid / dpad, slots = kBlock / dpad;
     float acc = 0.f;
-    if (c < d)
-        for (int r = lo + slot; r < hi; r += slots) acc += x[(size_t)r * d + c];
+    if (c < d && lo < hi)
+        for (int r0 = lo + slot; r0 < hi; r0 += 8 * slots) {       // eight loads in flight, added in row order
+            float a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 + u * slots;
+                a[u] = x[(size_t)(r < hi ? r : hi - 1) * d + c];
+                if (r >= hi) a[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += a[u];
+        }
     red[tid] = acc;
     __syncthreads();
     if (slot == 0 && c < d) {
