@@ -11,7 +11,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-__all__ = ["Batch", "random_batch", "powerlaw_batch", "config_batch", "CONFIGS"]
+__all__ = ["Batch", "random_batch", "powerlaw_batch", "single_graph_batch", "tu_batch", "config_batch", "CONFIGS"]
 
 
 @dataclass
@@ -107,6 +107,57 @@ def powerlaw_batch(n_graphs, n_lo, n_hi, alpha, seed, n_feat=None, n_classes=2) 
     return _finish(np.concatenate(rows), np.concatenate(cols), sizes, rng, n_feat, n_classes)
 
 
+def single_graph_batch(n_nodes, nnz, n_feat, n_classes, seed, density=0.01) -> Batch:
+    """One undirected graph with exactly ``nnz`` stored entries (``nnz / 2`` distinct edges, no self-loops) and
+    sparse binary features (each entry 1 with probability ``density``): the shape of a Planetoid citation graph
+    (``rwgnn2/rwgnn_dis_bias6.py:679-931`` loads Cora: 2708 nodes, 10556 entries, 1433 bag-of-words features)."""
+    rng = np.random.default_rng(seed)
+    want = nnz // 2
+    key = np.zeros(0, np.int64)
+    while key.size < want:
+        u = rng.integers(0, n_nodes, size=2 * want)
+        v = rng.integers(0, n_nodes, size=2 * want)
+        lo, hi = np.minimum(u, v), np.maximum(u, v)
+        k = (lo * n_nodes + hi)[lo != hi]
+        cand = np.concatenate([key, k])
+        _, first = np.unique(cand, return_index=True)
+        key = cand[np.sort(first)][:want]                    # first occurrences, in drawing order
+    lo, hi = key // n_nodes, key % n_nodes
+    sizes = np.array([n_nodes])
+    b = _finish(np.concatenate([lo, hi]), np.concatenate([hi, lo]), sizes, rng, 1, n_classes)
+    b.features = (rng.random((n_nodes, n_feat)) < density).astype(np.float32)
+    return b
+
+
+def tu_batch(name, first, count, root=None) -> Batch:
+    """Graphs [first, first + count) of a TU-format data set (``rwgnn2/utils.py:11-35``: ``_A.txt`` with 1-based
+    ``row, col`` pairs, ``_graph_indicator.txt``, ``_graph_labels.txt``), node degree as the single feature
+    (``utils.py:24``), labels renumbered 0..C-1 in sorted order (``LabelEncoder``, ``rwgnn2/main.py:39-40``)."""
+    import os
+    if root is None:
+        root = os.environ.get("RWK_TU_ROOT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
+            __file__))), "tests", "golden")
+    base = os.path.join(root, name, name)
+    gi = np.loadtxt(base + "_graph_indicator.txt", dtype=np.int64) - 1
+    edges = np.loadtxt(base + "_A.txt", dtype=np.int64, delimiter=",").reshape(-1, 2) - 1
+    labels = np.loadtxt(base + "_graph_labels.txt", dtype=np.int64)
+    _, y_all = np.unique(labels, return_inverse=True)
+    sizes_all = np.bincount(gi)
+    n = gi.size
+    key = np.unique(edges[:, 0] * n + edges[:, 1])
+    r, c = key // n, key % n
+    feats = np.bincount(r, minlength=n).astype(np.float32).reshape(n, 1)
+    whole = Batch(np.vstack([r, c]), np.ones(key.size, np.float32), feats, gi, y_all.astype(np.int64),
+                  sizes_all.astype(np.int64))
+    return whole.slice_graphs(first, min(first + count, sizes_all.size))
+
+
+#: rwgnn2/main.py:17-28 defaults
+_DEFAULT_HP = dict(input_dim=1, max_step=2, hidden_graphs=16, size_hidden_graphs=5, hidden_dim=4, penultimate_dim=32,
+                   normalize=False, n_classes=2, dropout=0.2)
+_PLANETOID_HP = dict(input_dim=64, max_step=3, hidden_graphs=8, size_hidden_graphs=4, hidden_dim=64,
+                     penultimate_dim=32, normalize=False, n_classes=7, dropout=0.2)
+
 #: hyper-parameters and generators of the benchmark configurations (BASELINE.json "configs")
 CONFIGS = {
     # PROTEINS / D&D-scale batches on one GPU: the configuration the headline metric is quoted on
@@ -121,13 +172,35 @@ CONFIGS = {
     "powerlaw": dict(hp=dict(input_dim=1, max_step=4, hidden_graphs=16, size_hidden_graphs=5, hidden_dim=4,
                              penultimate_dim=32, normalize=False, n_classes=2, dropout=0.2),
                      gen=lambda seed, scale=1: powerlaw_batch(64 * scale, 2000, 4000, 2.1, seed)),
-    # one Cora-scale graph
+    # one Cora-scale graph with dense features (kept from the first round's measurements)
     "single_graph": dict(hp=dict(input_dim=64, max_step=3, hidden_graphs=8, size_hidden_graphs=4, hidden_dim=64,
                                  penultimate_dim=32, normalize=False, n_classes=7, dropout=0.2),
                          gen=lambda seed, scale=1: random_batch(1, 2708 * scale, 2708 * scale, 3.9, seed,
                                                                 n_feat=64, n_classes=7)),
+    # D&D-like density of the same batch shape
+    "proteins1024_deg5": dict(hp=dict(_DEFAULT_HP), gen=lambda seed, scale=1: random_batch(1024 * scale, 100, 500, 5.0,
+                                                                                         seed)),
+    # power-law graphs at the wide hidden dimension, and four times as many of them
+    "powerlaw_d32": dict(hp=dict(_DEFAULT_HP, max_step=4, hidden_dim=32),
+                         gen=lambda seed, scale=1: powerlaw_batch(64 * scale, 2000, 4000, 2.1, seed)),
+    "powerlaw256": dict(hp=dict(_DEFAULT_HP, max_step=4),
+                        gen=lambda seed, scale=1: powerlaw_batch(256 * scale, 2000, 4000, 2.1, seed)),
+    "powerlaw256_d32": dict(hp=dict(_DEFAULT_HP, max_step=4, hidden_dim=32),
+                            gen=lambda seed, scale=1: powerlaw_batch(256 * scale, 2000, 4000, 2.1, seed)),
+    # Planetoid-scale single graphs (one graph: kernels only, BatchNorm1d cannot train on a batch of one):
+    # Cora and PubMed shapes with ~1 % sparse binary features, under the hyper-parameters of
+    # rwgnn2/rwgnn_dis_bias6.py:942-946 (8 hidden graphs x 4 nodes, hidden_dim 64, 3 steps) and under main.py's defaults
+    "cora": dict(hp=dict(_PLANETOID_HP, input_dim=1433, n_classes=7),
+                 gen=lambda seed, scale=1: single_graph_batch(2708, 10556, 1433, 7, seed)),
+    "cora_rwnn": dict(hp=dict(_DEFAULT_HP, input_dim=1433, n_classes=7),
+                      gen=lambda seed, scale=1: single_graph_batch(2708, 10556, 1433, 7, seed)),
+    "pubmed": dict(hp=dict(_PLANETOID_HP, input_dim=500, n_classes=3),
+                   gen=lambda seed, scale=1: single_graph_batch(19717, 88648, 500, 3, seed)),
+    "pubmed_rwnn": dict(hp=dict(_DEFAULT_HP, input_dim=500, n_classes=3),
+                        gen=lambda seed, scale=1: single_graph_batch(19717, 88648, 500, 3, seed)),
+    # the reference's own CPU-runnable case: the first batch of 64 MUTAG graphs (1168 nodes, 2590 entries)
+    "mutag": dict(hp=dict(_DEFAULT_HP), gen=lambda seed, scale=1: tu_batch("MUTAG", 0, 64 * scale)),
 }
-
 
 def config_batch(name: str, seed: int, scale: int = 1) -> Batch:
     return CONFIGS[name]["gen"](seed, scale)

@@ -31,7 +31,8 @@ def rel(a, b):
     return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def build(name, dev, n_graphs=None, seed=1):
+def build(name, dev, n_graphs=None, seed=1, train=False):
+    """train=True: the configuration's own dropout rate, training mode (the mode the benchmark runs in)."""
     from gnn_amd import RW_NN
     from gnn_amd.synth import CONFIGS, config_batch
     hp = dict(CONFIGS[name]["hp"])
@@ -40,9 +41,20 @@ def build(name, dev, n_graphs=None, seed=1):
         b = b.slice_graphs(0, n_graphs)
     torch.manual_seed(3)
     m = RW_NN(hp["input_dim"], hp["max_step"], hp["hidden_graphs"], hp["size_hidden_graphs"], hp["hidden_dim"],
-              hp["penultimate_dim"], hp["normalize"], hp["n_classes"], 0.0, dev).to(dev)
-    m.eval()
+              hp["penultimate_dim"], hp["normalize"], hp["n_classes"], hp["dropout"] if train else 0.0, dev).to(dev)
+    m.train(train)
     return hp, b, m
+
+
+def check_gradients(got, want, n, floor_terms):
+    """Parameter gradients are sums over all N nodes of signed terms (the cotangent is random).  Rounding floor of
+    a float32 sum of N terms of magnitude t: about eps * sqrt(N) * t; relative to the result it is that over |sum|."""
+    for key, ref in want.items():
+        err = np.abs(got[key].cpu().numpy().astype(np.float64) - ref).max()
+        bound = TOL * np.abs(ref).max()
+        if key in floor_terms:
+            bound = max(bound, 6e-8 * np.sqrt(n) * 4 * floor_terms[key])
+        assert err <= bound, (key, err, bound, np.abs(ref).max())
 
 
 def oracle_inputs(b, m):
@@ -53,7 +65,11 @@ def oracle_inputs(b, m):
     return csr, x0, m.adj_hidden.detach().cpu().numpy(), m.features_hidden.detach().cpu().numpy()
 
 
-@pytest.mark.parametrize("name", ["proteins1024", "powerlaw", "stream_h64", "single_graph"])
+FORWARD_CONFIGS = ["proteins1024", "proteins1024_deg5", "powerlaw", "powerlaw_d32", "powerlaw256", "stream_h64",
+                   "single_graph", "cora", "cora_rwnn", "pubmed", "pubmed_rwnn", "mutag"]
+
+
+@pytest.mark.parametrize("name", FORWARD_CONFIGS)
 def test_forward_full_size_against_gram_closed_form(name, dev):
     hp, b, m = build(name, dev)
     adj, feats, gi, _ = b.to_torch(dev)
@@ -66,8 +82,10 @@ def test_forward_full_size_against_gram_closed_form(name, dev):
     assert np.array_equal(k.view(np.uint32), k2.view(np.uint32)), "forward must be bitwise reproducible"
 
 
-@pytest.mark.parametrize("name,n_graphs", [("proteins1024", None), ("powerlaw", None), ("stream_h64", 1024),
-                                           ("single_graph", None)])
+@pytest.mark.parametrize("name,n_graphs", [("proteins1024", None), ("proteins1024_deg5", None), ("powerlaw", None),
+                                           ("powerlaw_d32", None), ("powerlaw256_d32", 96), ("stream_h64", 1024),
+                                           ("single_graph", None), ("cora", None), ("cora_rwnn", None),
+                                           ("pubmed", None), ("pubmed_rwnn", None), ("mutag", None)])
 def test_backward_full_size_against_oracle_vjp(name, n_graphs, dev):
     hp, b, m = build(name, dev, n_graphs)
     adj, feats, gi, _ = b.to_torch(dev)
@@ -87,18 +105,9 @@ def test_backward_full_size_against_oracle_vjp(name, n_graphs, dev):
     got = {"features": feats.grad, "features_hidden": m.features_hidden.grad, "adj_hidden": m.adj_hidden.grad,
            "fc.bias": m.fc.bias.grad, "fc.weight": m.fc.weight.grad}
     # per-node gradient: no long sum, plain 1e-5
-    assert rel(got["features"].cpu().numpy(), want["features"]) < TOL
-    # parameter gradients: sums over all N nodes of signed terms (the cotangent is random).  Rounding floor of a
-    # float32 sum of N terms of magnitude t: about eps * sqrt(N) * t; relative to the result it is that over |sum|.
-    n = b.n_nodes
-    floor_terms = {"fc.bias": np.abs(d_pre).max(), "fc.weight": np.abs(d_pre).max() * np.abs(f64).max()}
-    for key in ("features_hidden", "adj_hidden", "fc.bias", "fc.weight"):
-        ref = want[key]
-        err = np.abs(got[key].cpu().numpy().astype(np.float64) - ref).max()
-        bound = TOL * np.abs(ref).max()
-        if key in floor_terms:
-            bound = max(bound, 6e-8 * np.sqrt(n) * 4 * floor_terms[key])
-        assert err <= bound, (key, err, bound, np.abs(ref).max())
+    assert rel(got["features"].cpu().numpy(), want.pop("features")) < TOL
+    check_gradients(got, want, b.n_nodes, {"fc.bias": np.abs(d_pre).max(),
+                                           "fc.weight": np.abs(d_pre).max() * np.abs(f64).max()})
     # bitwise reproducibility of the backward at full size
     g1 = m.features_hidden.grad.clone()
     m.zero_grad()
@@ -153,3 +162,85 @@ def test_merged_launches_equal_separate_launches_full_size(name, dev):
         fn.MERGED_LAUNCHES = True
     for a, c in zip(*runs):
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("name,n_graphs", [("proteins1024", None), ("proteins1024_deg5", None), ("powerlaw", None),
+                                           ("stream_h64", 1024), ("mutag", None)])
+def test_train_mode_full_size_mask_replay(name, n_graphs, dev):
+    """The benchmarked mode (dropout on, training) at the benchmarked size: the kernels' own keep mask is dumped and
+    must equal the oracle's restatement of the generator bit for bit; K and every gradient of the layer are then
+    replayed in float64 with that mask (model.py:58 applied to the (H, S, N) products) and compared to 1e-5."""
+    from gnn_amd import _lib
+    hp, b, m = build(name, dev, n_graphs, train=True)
+    p = float(hp["dropout"])
+    assert p > 0.0 and m.training
+    seed, offset = 0x0123456789ABCDE, (1 << 33) + 17          # the offset's high word enters the generator's key
+    m.seed_dropout(seed, offset)
+    adj, feats, gi, _ = b.to_torch(dev)
+    feats = feats.clone().requires_grad_(True)
+    h, s, steps = hp["hidden_graphs"], hp["size_hidden_graphs"], hp["max_step"]
+
+    keep_dev = torch.empty((steps, h, s, b.n_nodes), dtype=torch.uint8, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.rwk_dropout_mask(m._rng_state.data_ptr(), b.n_nodes, h, s, steps, p, keep_dev.data_ptr(),
+                                    _lib.current_stream(dev)), "rwk_dropout_mask")
+    keep = O.dropout_keep(seed, offset, b.n_nodes, h, s, steps, p)
+    assert np.array_equal(keep_dev.cpu().numpy().astype(bool), keep)
+    del keep_dev
+
+    k = m.rw_features(adj, feats, gi)
+    assert int(m._rng_state[1].item()) == offset + 1         # the launch advanced the device-side offset
+    csr, x0, ah, fh = oracle_inputs(b, m)
+    k_ref = O.rw_kernel_forward(csr, x0, ah, fh, b.graph_indicator, steps, hp["normalize"], keep=keep, drop_p=p)
+    assert rel(k.detach().cpu().numpy(), k_ref) < TOL
+
+    rng = np.random.default_rng(6)
+    dk = rng.normal(size=k_ref.shape).astype(np.float32)
+    k.backward(torch.from_numpy(dk).to(dev))
+    d_x0, d_adj, d_feat = O.rw_kernel_backward(csr, x0, ah, fh, b.graph_indicator, steps, dk, hp["normalize"],
+                                               keep=keep, drop_p=p)
+    d_pre = d_x0 * x0 * (1 - x0)
+    w64 = m.fc.weight.detach().cpu().numpy().astype(np.float64)
+    f64 = b.features.astype(np.float64)
+    assert rel(feats.grad.cpu().numpy(), d_pre @ w64) < TOL
+    got = {"features_hidden": m.features_hidden.grad, "adj_hidden": m.adj_hidden.grad, "fc.bias": m.fc.bias.grad,
+           "fc.weight": m.fc.weight.grad}
+    want = {"features_hidden": d_feat, "adj_hidden": d_adj, "fc.bias": d_pre.sum(0), "fc.weight": d_pre.T @ f64}
+    check_gradients(got, want, b.n_nodes, {"fc.bias": np.abs(d_pre).max(),
+                                           "fc.weight": np.abs(d_pre).max() * np.abs(f64).max()})
+
+
+@pytest.mark.parametrize("name", ["proteins1024", "stream_h64"])
+def test_graph_replay_equals_eager_full_size_with_dropout(name, dev):
+    """Same seed, same batch, dropout on: the training step replayed from a captured HIP graph and the step launched
+    eagerly run the same kernels on the same generator offsets, so after the same number of steps the loss, the
+    gradients and the updated parameters are equal bit for bit."""
+    from gnn_amd import RW_NN
+    from gnn_amd.synth import CONFIGS, config_batch
+    from gnn_amd.trainer import Trainer
+    hp = dict(CONFIGS[name]["hp"])
+    batch_t = config_batch(name, 1).to_torch(dev)
+
+    def trainer():
+        torch.manual_seed(0)
+        m = RW_NN(hp["input_dim"], hp["max_step"], hp["hidden_graphs"], hp["size_hidden_graphs"], hp["hidden_dim"],
+                  hp["penultimate_dim"], hp["normalize"], hp["n_classes"], hp["dropout"], dev).to(dev)
+        m.train()
+        m.seed_dropout(4321)
+        return Trainer(m, batch_t)
+
+    eager, graph = trainer(), trainer()
+    graph.capture()                       # three eager warm-up steps, then the capture
+    for _ in range(3):
+        eager.step_eager()
+    for _ in range(3):
+        eager.step_eager()
+        graph.step_graph()
+        torch.cuda.synchronize()
+        assert torch.equal(eager.loss, graph.loss)
+        assert torch.equal(eager.bucket.flat, graph.bucket.flat)
+    assert torch.equal(eager.model._rng_state, graph.model._rng_state)
+    for pe, pg in zip(eager.model.parameters(), graph.model.parameters()):
+        assert torch.equal(pe, pg)
+    for be, bg in zip(eager.model.buffers(), graph.model.buffers()):
+        assert torch.equal(be, bg)
