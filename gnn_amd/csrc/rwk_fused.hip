@@ -745,6 +745,9 @@ const char *rwk_error_string(int code) {
         case RWK_E_SIZE: return "a size argument is out of range";
         case RWK_E_UNSUPPORTED: return "hyper-parameters not supported by the kernels (need H <= 64, D <= 64, max_step <= 4)";
         case RWK_E_ALIGN: return "a pointer is misaligned";
+        case RWK_E_STATIC_SIZE:
+            return "the input exceeds the library's fixed device scratch (rwk_reduce_rows_static: more than "
+                   "RWK_REDUCE_ROWS_STATIC_MAX_V columns); use the entry point that takes a workspace";
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);
     return "unknown error";

@@ -5,6 +5,8 @@
 // a GEMM library spends ~0.7 ms on the N-long weight-gradient reduction, the kernels here stream it
 // at HBM rate: forward reads N*F and writes N*D floats; backward reads 2*N*D + N*F floats and
 // writes per-workgroup partial sums of (dW | db) which rwk_reduce_rows adds in a fixed order.
+#include <mutex>
+
 #include "rwk_project_body.h"
 #include "rwk_reduce_body.h"
 
@@ -208,6 +210,53 @@ int rwk_reduce_rows(const float *in, int64_t p, int64_t v, float *out, float *wo
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------
+// rwk_reduce_rows for callers that cannot allocate: the 32 x v level-1 sums live in a file-scope device
+// array instead of a caller-owned workspace.  Every GPU the library runs on holds its own copy of the array
+// (2 MiB) at its own address until the process ends; the address is looked up once per device, with that
+// device current, and only that address (never the array's name) is handed to kernels.
+// ---------------------------------------------------------------------------------------
+constexpr long long kStaticMaxV = RWK_REDUCE_ROWS_STATIC_MAX_V;
+static __device__ __align__(256) float scratch[kMaxFinalRows * kStaticMaxV];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex scratch_mutex;
+float *scratch_ptr[kMaxDevices] = {};        // device address of `scratch` on each GPU, nullptr = not looked up yet
+
+int scratch_for_current_device(float **out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= kMaxDevices) return RWK_E_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(scratch_mutex);
+    if (scratch_ptr[dev] == nullptr) {
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return (int)e;
+        if (p == nullptr) return RWK_E_NULL;
+        scratch_ptr[dev] = static_cast<float *>(p);
+    }
+    *out = scratch_ptr[dev];
+    return RWK_OK;
+}
+}  // namespace
+
+extern "C" int rwk_reduce_rows_static(const float *in, int64_t p, int64_t v, float *out, rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(in);
+    RWK_REQUIRE_PTR(out);
+    if (p <= 0 || v <= 0) return RWK_E_SIZE;
+    float *ws = nullptr;
+    if (rwk_reduce_rows_workspace(p, v) > 0) {
+        // every element of the 32 x v level-1 block is written by the first launch (row blocks without rows write
+        // zeros), so nothing of an earlier call's contents is read and nothing needs clearing
+        if (v > kStaticMaxV) return RWK_E_STATIC_SIZE;
+        const int rc = scratch_for_current_device(&ws);
+        if (rc != RWK_OK) return rc;
+    }
+    return rwk_reduce_rows(in, p, v, out, ws, stream);
+}
 
 template <bool SIGMOID>
 static int project_forward_impl(const float *features, const float *weight, const float *bias, int64_t n, int64_t f,

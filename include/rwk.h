@@ -38,6 +38,7 @@ extern "C" {
 #define RWK_E_SIZE (-2)        /* a size is negative, zero where it must not be, or too large */
 #define RWK_E_UNSUPPORTED (-3) /* hyper-parameters outside what the kernels are built for */
 #define RWK_E_ALIGN (-4)       /* a pointer is not aligned as documented */
+#define RWK_E_STATIC_SIZE (-5) /* the input needs more of the library's fixed device scratch than it holds */
 
 typedef void *rwk_stream_t;
 
@@ -354,6 +355,16 @@ int rwk_reduce_rows(const float *in, int64_t p, int64_t v, float *out, float *wo
  * after it (p itself when p <= 32, else 32); rwk_hidden_backward adds up to 32 rows itself. */
 int64_t rwk_reduce_rows_level1(int64_t p);
 int rwk_reduce_rows_to32(const float *in, int64_t p, int64_t v, float *out32, rwk_stream_t stream);
+/* rwk_reduce_rows for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same kernels, same order of
+ * additions, same bits as rwk_reduce_rows; the 32 x v level-1 sums live in a device array of the library itself
+ * (RWK_REDUCE_ROWS_STATIC_MAX_V columns, 2 MiB, held by every GPU the library runs on until the process ends)
+ * instead of a caller-owned workspace.  v above that limit (when a workspace is needed at all, i.e. p > 32 and
+ * (v > 64 or p > 2^20)) returns RWK_E_STATIC_SIZE.  Calls no hipMalloc / hipFree.  All calls on one GPU share that
+ * GPU's array: calls that overlap on one GPU (different streams, or different host threads without stream
+ * order between them) race. */
+#define RWK_REDUCE_ROWS_STATIC_MAX_V 16384
+int rwk_reduce_rows_static(const float *in, int64_t p, int64_t v, float *out, rwk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Adam over one flat parameter buffer (torch.optim.Adam semantics, rwgnn2/main.py:79,87):
