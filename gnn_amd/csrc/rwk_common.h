@@ -28,15 +28,24 @@ struct RwkPhilox4 {
     uint32_t x, y, z, w;
 };
 
+// a ^ b ^ c: one v_bitop3_b32 on the device (the compiler leaves the round's two-step XOR as two instructions)
+__host__ __device__ static inline uint32_t rwk_xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+    return a ^ b ^ c;
+#endif
+}
+
 __host__ __device__ static inline RwkPhilox4 rwk_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
                                                                uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n0 = rwk_xor3((uint32_t)(p1 >> 32), c1, k0);
         const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n2 = rwk_xor3((uint32_t)(p0 >> 32), c3, k1);
         const uint32_t n3 = (uint32_t)p0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u;
