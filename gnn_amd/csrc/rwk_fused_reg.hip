@@ -104,6 +104,19 @@ __device__ inline float dot4(const float (&a)[DP], const float (&b)[DP]) {
     return acc;
 }
 
+
+// A SIMD serves the wavefront of highest priority first and the oldest among equals.  With equal priorities the
+// wavefronts of the single round of workgroups finish one after the other, and the last one runs alone at half the
+// SIMD's issue rate.  Lowering a wavefront's priority as it advances through its stream (3 for the first half of
+// its positions, 2 up to three quarters, 1 up to seven eighths, then 0) makes the wavefronts that are behind go
+// first at each of these marks, so they enter the last eighth together and end close to each other.
+__device__ inline void progress_priority(int done, int total) {
+    if (done == 0) __builtin_amdgcn_s_setprio(3);
+    else if (done == total >> 1) __builtin_amdgcn_s_setprio(2);
+    else if (done == total - (total >> 2)) __builtin_amdgcn_s_setprio(1);
+    else if (done == total - (total >> 3)) __builtin_amdgcn_s_setprio(0);
+}
+
 template <int LT, int ST>
 __device__ inline void load_z(const float *__restrict__ z, int h, int hh, int d, float (&zr)[LT][ST][DP]) {
     // every load is unconditional (a load under a per-element condition makes the compiler branch
@@ -140,28 +153,40 @@ struct Tile {
     int node[kBlock];
 };
 
-// Slots past the end of a stream carry zero rows (so they contribute nothing), node = -1, and the graph id
-// of the stream's last position (so they never trigger a flush): the loops below need no validity branch.
+// A thread's own slot of a tile, fetched into registers one tile ahead of its use (the loads stay in flight while
+// the previous tile is being worked on) and written to LDS afterwards.  Slots past the end of a stream carry zero
+// rows (so they contribute nothing), node = -1, and the graph id of the stream's last position (so they never
+// trigger a flush): the loops below need no validity branch.  Every load is unconditional, from a clamped
+// position: a select on a value makes the wavefront wait for its load where the select stands, so validity is
+// applied when the slot is written to LDS.
 template <int LT>
-__device__ inline void load_tile(Tile<LT> &tile, const float *__restrict__ x, const int *__restrict__ gid,
-                                 const int *__restrict__ perm, int p, int end, bool has_stream, int d,
-                                 size_t step_stride) {
-    const int t = threadIdx.x;
-    const bool valid = has_stream && p < end;
-    int node = -1, g = -1;
-    if (has_stream) {
-        const int pc = valid ? p : end - 1;
-        g = gid[pc];
-        if (valid) node = perm ? perm[p] : p;
-    }
-    tile.node[t] = node;
-    tile.gid[t] = g;
+struct Slot {
+    float x[LT][DP];
+    int gid, node;
+    bool valid;
+};
+
+template <int LT>
+__device__ inline void fetch_slot(Slot<LT> &sl, const float *__restrict__ x, const int *__restrict__ gid,
+                                  const int *__restrict__ perm, int p, int end, bool has_stream, int d,
+                                  size_t step_stride) {
+    sl.valid = has_stream && p < end;
+    const int pc = has_stream ? (sl.valid ? p : end - 1) : 0;         // always a position of the batch
+    sl.gid = gid[pc];
+    sl.node = perm ? perm[pc] : pc;
 #pragma unroll
-    for (int i = 0; i < LT; ++i) {
-        float r[DP] = {0.f, 0.f, 0.f, 0.f};
-        if (valid) load_x(x + i * step_stride + (size_t)node * d, d, r);
-        tile.x[i][t] = make_float4(r[0], r[1], r[2], r[3]);
-    }
+    for (int i = 0; i < LT; ++i) load_x(x + i * step_stride + (size_t)sl.node * d, d, sl.x[i]);
+}
+
+template <int LT>
+__device__ inline void put_slot(Tile<LT> &tile, const Slot<LT> &sl, bool has_stream) {
+    const int t = threadIdx.x;
+    tile.node[t] = sl.valid ? sl.node : -1;
+    tile.gid[t] = has_stream ? sl.gid : -1;
+#pragma unroll
+    for (int i = 0; i < LT; ++i)
+        tile.x[i][t] = sl.valid ? make_float4(sl.x[i][0], sl.x[i][1], sl.x[i][2], sl.x[i][3])
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // HPT: lanes per stream as a compile-time constant (0 = use the run-time value hp_arg)
@@ -174,7 +199,7 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
                uint32_t t1, const unsigned long long *__restrict__ rng, float *__restrict__ k_partials) {
     constexpr int NC = (LT * ST + 14) / 15;
     const int hp = HPT ? HPT : hp_arg;
-    __shared__ Tile<LT> tile;
+    __shared__ Tile<LT> tiles[2];                       // tile t in tiles[t & 1]; the other one is being filled
     const int tid = threadIdx.x;
     const int lane_h = tid % hp;
     const int hh = lane_h < h ? lane_h : h - 1;
@@ -184,12 +209,14 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
     const bool has_stream = start_ll < n;
     const int start = has_stream ? (int)start_ll : 0;
     const int end = has_stream ? (int)(start_ll + stream_len < n ? start_ll + stream_len : n) : 0;
+    const size_t step_stride = (size_t)n * d;
+    Slot<LT> slot;
+    fetch_slot<LT>(slot, x, gid, perm, start + lane_h, end, has_stream, d, step_stride);
     float zr[LT][ST][DP];
     load_z<LT, ST>(z, h, hh, d, zr);
     DropCfg cfg;
     if (DROP) cfg = load_cfg(rng, t0, t1);
     const int lh = LT * h;
-    const size_t step_stride = (size_t)n * d;
 
     constexpr int SK = KS ? ST : 1;                 // accumulators per step
     float acc[LT][SK];
@@ -206,12 +233,16 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
             for (int q = 0; q < SK; ++q) dst[(size_t)i * h * SK + q] = acc[i][q];
     };
 
-    for (int base = 0; base < stream_len; base += hp) {
-        __syncthreads();
-        load_tile<LT>(tile, x, gid, perm, start + base + lane_h, end, has_stream, d, step_stride);
-        __syncthreads();
+    put_slot<LT>(tiles[0], slot, has_stream);
+    __syncthreads();
+    int buf = 0;
+    for (int base = 0; base < stream_len; base += hp, buf ^= 1) {
+        const Tile<LT> &tile = tiles[buf];
+        const bool more = base + hp < stream_len;
+        if (more) fetch_slot<LT>(slot, x, gid, perm, start + base + hp + lane_h, end, has_stream, d, step_stride);
         const int jmax = stream_len - base < hp ? stream_len - base : hp;
         for (int j = 0; j < jmax; ++j) {
+            progress_priority(base + j, stream_len);
             const int node = tile.node[group0 + j];
             const int g = tile.gid[group0 + j];
             if (g != g_cur) {
@@ -251,6 +282,10 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
 #pragma unroll
                 for (int q = 0; q < SK; ++q) acc[i][q] += node_acc[i][q];
         }
+        if (more) {
+            put_slot<LT>(tiles[buf ^ 1], slot, has_stream);     // its readers all passed the previous barrier
+            __syncthreads();
+        }
     }
     if (g_cur >= 0 && lane_h < h) flush(g_cur);
 }
@@ -267,7 +302,7 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     const int hp = HPT ? HPT : hp_arg;
     constexpr int V = LT * ST * DP;               // gradient values per lane
     constexpr int CH = V < 16 ? V : 16;           // values staged per LDS round of the final reduction
-    __shared__ Tile<LT> tile;
+    __shared__ Tile<LT> tiles[2];                 // tile t in tiles[t & 1]; the other one is being filled
     __shared__ float red[CH][kBlock];
 
     RWK_STAMP_DECL();
@@ -281,12 +316,14 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     const bool has_stream = start_ll < n;
     const int start = has_stream ? (int)start_ll : 0;
     const int end = has_stream ? (int)(start_ll + stream_len < n ? start_ll + stream_len : n) : 0;
+    const size_t step_stride = (size_t)n * d;
+    Slot<LT> slot;
+    fetch_slot<LT>(slot, x, gid, perm, start + lane_h, end, has_stream, d, step_stride);
     float zr[LT][ST][DP];
     load_z<LT, ST>(z, h, hh, d, zr);
     DropCfg cfg;
     if (DROP) cfg = load_cfg(rng, t0, t1);
     const int lh = LT * h;
-    const size_t step_stride = (size_t)n * d;
 
     float dz[V];
 #pragma unroll
@@ -300,22 +337,26 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     int g_cur = -1;
 
     // where this lane puts its dX total of the halving reduction: float (idx % 4) of row (idx / 4) of slot group0 + j
-    float *red_dst = nullptr;
+    int red_off = 0;
     if (HPT == 16 && (LT == 2 || LT == 4)) {
         const int idx = rwk_halving_index<(LT == 4 ? 16 : 8)>(lane_h);
-        red_dst = reinterpret_cast<float *>(&tile.x[(idx / DP) % LT][group0]) + idx % DP;
+        red_off = (((idx / DP) % LT) * kBlock + group0) * DP + idx % DP;      // in floats from &tile.x[0][0]
     }
-    for (int base = 0; base < stream_len; base += hp) {
-        const int my_p = start + base + lane_h;          // the slot this lane loads and later stores
+    put_slot<LT>(tiles[0], slot, has_stream);
+    __syncthreads();
+    int buf = 0;
+    for (int base = 0; base < stream_len; base += hp, buf ^= 1) {
+        Tile<LT> &tile = tiles[buf];
+        float *red_dst = reinterpret_cast<float *>(&tile.x[0][0]) + red_off;
         RWK_STAMP_AT(0);
-        __syncthreads();
-        load_tile<LT>(tile, x, gid, perm, my_p, end, has_stream, d, step_stride);
-        __syncthreads();
-        const int my_node = tile.node[tid];
+        const int my_node = tile.node[tid];              // the slot this lane loaded and later stores
+        const bool more = base + hp < stream_len;
+        if (more) fetch_slot<LT>(slot, x, gid, perm, start + base + hp + lane_h, end, has_stream, d, step_stride);
         RWK_STAMP_AT(1);
         // every lane of the wavefront runs all hp iterations: the DPP butterfly needs them all
         const int jmax = stream_len - base < hp ? stream_len - base : hp;
         for (int j = 0; j < jmax; ++j) {
+            progress_priority(base + j, stream_len);
             const int node = tile.node[group0 + j];
             const int g = tile.gid[group0 + j];
             float xr[LT][DP], dxr[LT][DP];
@@ -404,6 +445,10 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                         if (k < d) row[k] = mine_i[k];
                 }
             }
+        }
+        if (more) {
+            put_slot<LT>(tiles[buf ^ 1], slot, has_stream);     // its readers all passed the previous barrier
+            __syncthreads();
         }
     }
 
