@@ -74,6 +74,16 @@ SIGNATURES = {
                                            _P]),
     "rwk_project_hidden_backward": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64,
                                             _I64, _P, _P, _P]),
+    "rwk_spmm_project_backward_blocks": (_I64, [_I64]),
+    "rwk_spmm_project_backward": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P,
+                                          _P]),
+    "rwk_hidden_backward_reduce": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _I64, _I64, _P,
+                                           _P]),
+    "rwk_fused_reduce_stats_rows": (_I64, [_I64]),
+    "rwk_fused_reduce_stats_blocks": (_I64, [_I64]),
+    "rwk_fused_reduce_stats": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, c_float, c_int, _P, _P, _P, _P, _P]),
+    "rwk_head_apply_loss": (c_int, [_P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, c_float, c_float, _P, _I64, _P,
+                                    _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rwk_reduce_rows_workspace": (_I64, [_I64, _I64]),
     "rwk_reduce_rows": (c_int, [_P, _I64, _I64, _P, _P, _P]),
     "rwk_reduce_rows_level1": (_I64, [_I64]),

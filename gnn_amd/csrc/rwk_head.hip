@@ -62,6 +62,7 @@ __host__ __device__ inline int head_blocks(long long g) {
 // every column (a round trip to L2 per 64 of them and per 32 columns), so there are fewer of them than row
 // tiles: the statistics pass itself only reads K once more however it is cut.
 constexpr int kMaxStatsBlocks = 64;
+constexpr int kMaxFusedStatsBlocks = 128;    // block partials the fused K reduction (kreduce_stats_kernel) leaves
 __host__ __device__ inline int head_stats_blocks(long long g) {
     const int b = head_blocks(g);
     return b < kMaxStatsBlocks ? b : kMaxStatsBlocks;
@@ -128,17 +129,145 @@ head_stats_kernel(const float *__restrict__ k, long long g, int c, float *__rest
     }
 }
 
+// The per-graph slot reduction of the random-walk layer (K[g, col] = scale * sum of the slots of graph g, in stream
+// order: what fused_reduce_kernel computes, added in the same order) and the batch statistics of the K it writes,
+// in one launch: block b owns rows [b * rows_per_block, (b + 1) * rows_per_block) and leaves
+// partials[b] = {count, mean[C], M2[C]} of them.  A thread owns one column and every (256 / C)-th row of the block;
+// it works on two of its rows at a time so that their segment bounds, and then sixteen slots of each, are in flight
+// together.  With at most two rows per thread (the usual case) the values stay in registers for the second pass; otherwise
+// the second pass reads back what the same thread stored.
+constexpr int kKrRows = 2, kKrSlots = 16;
+
+__global__ void __launch_bounds__(kBlock)
+kreduce_stats_kernel(const float *__restrict__ k_partials, const int *__restrict__ seg_ptr,
+                     const float *__restrict__ counts_f32, long long g, int c, int stream_len, float scale,
+                     int normalize, int rows_per_block, float *k, float *__restrict__ partials,
+                     unsigned long long *rng_state, unsigned long long *rng_used) {
+    __shared__ float red[kBlock];
+    __shared__ float s_mean[kMaxC];
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0 && rng_state != nullptr && rng_used != nullptr) {
+        const unsigned long long seed = rng_state[0], off = rng_state[1];
+        rng_used[0] = seed;
+        rng_used[1] = off;
+        rng_state[1] = off + 1ull;
+    }
+    const int tpc = kBlock / c;                    // row lanes per column (c <= 256)
+    const int col = tid % c, rl = tid / c;
+    const bool lane_ok = rl < tpc;
+    const long long r_lo = (long long)blockIdx.x * rows_per_block;
+    const long long r_hi = r_lo + rows_per_block < g ? r_lo + rows_per_block : g;
+    const long long count = r_hi > r_lo ? r_hi - r_lo : 0;
+    const int chunk_rows = kKrRows * tpc;
+    const bool one_chunk = rows_per_block <= chunk_rows;
+    float first_vals[kKrRows] = {0.f, 0.f};
+    float sum = 0.f;
+    for (long long rb = r_lo; rb < r_hi; rb += chunk_rows) {          // uniform over the workgroup
+        long long rows[kKrRows];
+        bool ok[kKrRows];
+        int cur[kKrRows], last[kKrRows];
+#pragma unroll
+        for (int q = 0; q < kKrRows; ++q) {
+            const long long r = rb + rl + (long long)q * tpc;
+            ok[q] = lane_ok && r < r_hi;
+            rows[q] = ok[q] ? r : r_lo;                               // a row of this block either way
+            cur[q] = seg_ptr[rows[q]] / stream_len;
+            last[q] = (seg_ptr[rows[q] + 1] - 1) / stream_len;
+        }
+        float acc[kKrRows] = {0.f, 0.f};
+        bool more = true;
+        while (more) {
+            float a[kKrRows][kKrSlots];
+#pragma unroll
+            for (int q = 0; q < kKrRows; ++q) {
+                const float *src = k_partials + (size_t)rows[q] * c + col;
+#pragma unroll
+                for (int u = 0; u < kKrSlots; ++u) {
+                    const int cs = cur[q] + u;
+                    a[q][u] = src[(size_t)(cs <= last[q] ? cs : last[q]) * c];
+                    if (cs > last[q]) a[q][u] = 0.f;                  // past the row's last slot: adds an exact zero
+                }
+            }
+            more = false;
+#pragma unroll
+            for (int q = 0; q < kKrRows; ++q) {
+#pragma unroll
+                for (int u = 0; u < kKrSlots; ++u) acc[q] += a[q][u];
+                cur[q] += kKrSlots;
+                more = more || cur[q] <= last[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kKrRows; ++q) {
+            float v = acc[q] * scale;
+            if (normalize) v /= counts_f32[rows[q]];
+            if (ok[q]) {
+                k[rows[q] * c + col] = v;
+                sum += v;
+                if (one_chunk) first_vals[q] = v;
+            }
+        }
+    }
+    red[tid] = lane_ok ? sum : 0.f;
+    __syncthreads();
+    if (tid < c) {
+        float sacc = 0.f;
+        for (int q = 0; q < tpc; ++q) sacc += red[q * c + tid];
+        s_mean[tid] = count > 0 ? sacc / (float)count : 0.f;
+    }
+    __syncthreads();
+    const float mu = s_mean[col];
+    float m2 = 0.f;
+    if (one_chunk) {
+#pragma unroll
+        for (int q = 0; q < kKrRows; ++q) {
+            const long long r = r_lo + rl + (long long)q * tpc;
+            if (lane_ok && r < r_hi) {
+                const float dv = first_vals[q] - mu;
+                m2 = fmaf(dv, dv, m2);
+            }
+        }
+    } else if (lane_ok) {
+        for (long long rb = r_lo + rl; rb < r_hi; rb += chunk_rows) {
+            float v[kKrRows];
+#pragma unroll
+            for (int q = 0; q < kKrRows; ++q) {
+                const long long r = rb + (long long)q * tpc;
+                v[q] = k[(r < r_hi ? r : r_lo + rl) * c + col];
+            }
+#pragma unroll
+            for (int q = 0; q < kKrRows; ++q) {
+                if (rb + (long long)q * tpc < r_hi) {
+                    const float dv = v[q] - mu;
+                    m2 = fmaf(dv, dv, m2);
+                }
+            }
+        }
+    }
+    red[tid] = lane_ok ? m2 : 0.f;
+    __syncthreads();
+    float *out = partials + (size_t)blockIdx.x * (1 + 2 * c);
+    if (tid == 0) out[0] = (float)count;
+    if (tid < c) {
+        float sacc = 0.f;
+        for (int q = 0; q < tpc; ++q) sacc += red[q * c + tid];
+        out[1 + tid] = s_mean[tid];
+        out[1 + c + tid] = sacc;
+    }
+}
+
 // Batch statistics of one column from the per-block partials (count, mean, M2 about the block mean), computed by
 // 8 cooperating lanes (lane8 = 0..7 of an aligned group) with the pairwise-variance identity applied once over all
 // blocks:  mean = sum_b n_b mean_b / N,  M2 = sum_b (M2_b + n_b (mean_b - mean)^2).  Lane l adds blocks l, l+8, ...
 // in order, the eight sums are added in a butterfly whose operand pairs are the same on every lane, so every lane
 // (and every workgroup) ends with the same bits.  Two divisions per column; the partials are fetched eight blocks
 // at a time (24 loads in flight) - a load per step would cost a round trip to L2 each.
+constexpr int kChunk = 16;       // blocks per lane and chunk: 128 blocks (the most the fused K reduction leaves) in one
 struct StatsChunk {
-    float n[8], mean[8], m2[8];
+    float n[kChunk], mean[kChunk], m2[kChunk];
     __device__ inline void load(const float *__restrict__ partials, int n_blocks, int c, int col, int b0) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kChunk; ++u) {
             const int b = b0 + 8 * u;
             const float *p = partials + (size_t)(b < n_blocks ? b : n_blocks - 1) * (1 + 2 * c);
             n[u] = p[0];
@@ -163,15 +292,15 @@ __device__ inline float merge_stats8(const float *__restrict__ partials, int n_b
                                      const StatsChunk &first, float *var) {
     float sn = 0.f, sm = 0.f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < kChunk; ++u) {
         sn += first.n[u];
         sm = fmaf(first.n[u], first.mean[u], sm);
     }
-    for (int b0 = lane8 + 64; b0 < n_blocks; b0 += 64) {
+    for (int b0 = lane8 + 8 * kChunk; b0 < n_blocks; b0 += 8 * kChunk) {
         StatsChunk next;
         next.load(partials, n_blocks, c, col, b0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kChunk; ++u) {
             sn += next.n[u];
             sm = fmaf(next.n[u], next.mean[u], sm);
         }
@@ -181,15 +310,15 @@ __device__ inline float merge_stats8(const float *__restrict__ partials, int n_b
     const float mean = sn > 0.f ? sm / sn : 0.f;
     float q = 0.f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < kChunk; ++u) {
         const float dv = first.mean[u] - mean;
         q += fmaf(first.n[u] * dv, dv, first.m2[u]);
     }
-    for (int b0 = lane8 + 64; b0 < n_blocks; b0 += 64) {
+    for (int b0 = lane8 + 8 * kChunk; b0 < n_blocks; b0 += 8 * kChunk) {
         StatsChunk next;
         next.load(partials, n_blocks, c, col, b0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kChunk; ++u) {
             const float dv = next.mean[u] - mean;
             q += fmaf(next.n[u] * dv, dv, next.m2[u]);
         }
@@ -770,12 +899,83 @@ int rwk_head_forward(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc
                                  invstd_out, h1d_out, out, nullptr, nullptr, stream_);
 }
 
+// n_stats_ready > 0: `stats` already holds that many block partials (rwk_fused_reduce_stats wrote them and drew
+// the generator state into rng_used), so the statistics launch is skipped
+static int head_forward_impl(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
+                             const float *bn_b, float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                             float momentum, float eps, int training, float *stats, int n_stats_ready, const float *w1,
+                             const float *b1, const float *w2, const float *b2, float drop_p, uint64_t *rng_state,
+                             uint64_t *rng_used, float *mean_out, float *invstd_out, float *h1d_out, float *out,
+                             const int64_t *labels, float *loss_partials, rwk_stream_t stream_);
+
 int rwk_head_forward_loss(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
                           const float *bn_b, float *running_mean, float *running_var, int64_t *num_batches_tracked,
                           float momentum, float eps, int training, float *stats, const float *w1, const float *b1,
                           const float *w2, const float *b2, float drop_p, uint64_t *rng_state, uint64_t *rng_used,
                           float *mean_out, float *invstd_out, float *h1d_out, float *out, const int64_t *labels,
                           float *loss_partials, rwk_stream_t stream_) {
+    return head_forward_impl(k, g, c, p, nc, bn_w, bn_b, running_mean, running_var, num_batches_tracked, momentum, eps,
+                             training, stats, 0, w1, b1, w2, b2, drop_p, rng_state, rng_used, mean_out, invstd_out,
+                             h1d_out, out, labels, loss_partials, stream_);
+}
+
+int rwk_head_apply_loss(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
+                        const float *bn_b, float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                        float momentum, float eps, const float *stats, int64_t n_stats, const float *w1,
+                        const float *b1, const float *w2, const float *b2, float drop_p, const uint64_t *rng_used,
+                        float *mean_out, float *invstd_out, float *h1d_out, float *out, const int64_t *labels,
+                        float *loss_partials, rwk_stream_t stream_) {
+    RWK_REQUIRE_PTR(stats);
+    if (n_stats < 1 || n_stats > kMaxFusedStatsBlocks) return RWK_E_SIZE;
+    if (drop_p > 0.f) RWK_REQUIRE_PTR(rng_used);
+    return head_forward_impl(k, g, c, p, nc, bn_w, bn_b, running_mean, running_var, num_batches_tracked, momentum, eps,
+                             1, const_cast<float *>(stats), (int)n_stats, w1, b1, w2, b2, drop_p,
+                             const_cast<uint64_t *>(rng_used), const_cast<uint64_t *>(rng_used), mean_out, invstd_out,
+                             h1d_out, out, labels, loss_partials, stream_);
+}
+
+// at most kMaxFusedStatsBlocks blocks of at least eight rows
+int64_t rwk_fused_reduce_stats_rows(int64_t g) {
+    if (g < 1) return 0;
+    const int64_t rows = (g + kMaxFusedStatsBlocks - 1) / kMaxFusedStatsBlocks;
+    return rows < 8 ? (g < 8 ? g : 8) : rows;
+}
+
+int64_t rwk_fused_reduce_stats_blocks(int64_t g) {
+    if (g < 1) return 0;
+    const int64_t rows = rwk_fused_reduce_stats_rows(g);
+    return (g + rows - 1) / rows;
+}
+
+int rwk_fused_reduce_stats(const float *k_partials, const int32_t *seg_ptr, const float *counts_f32, int64_t n_graphs,
+                           int64_t h, int64_t max_step, int64_t stream_len, float drop_p, int normalize, float *k,
+                           float *stats, uint64_t *rng_state, uint64_t *rng_used, rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(k_partials);
+    RWK_REQUIRE_PTR(seg_ptr);
+    RWK_REQUIRE_PTR(k);
+    RWK_REQUIRE_PTR(stats);
+    if (normalize) RWK_REQUIRE_PTR(counts_f32);
+    if ((rng_state == nullptr) != (rng_used == nullptr)) return RWK_E_NULL;
+    if (n_graphs <= 0 || h <= 0 || max_step <= 0 || stream_len <= 0 || !(drop_p >= 0.f && drop_p < 1.f))
+        return RWK_E_SIZE;
+    const int64_t c = h * max_step;
+    if (c > kMaxC || n_graphs >= (int64_t)1 << 40) return RWK_E_UNSUPPORTED;
+    const float scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const int64_t rows = rwk_fused_reduce_stats_rows(n_graphs);
+    hipLaunchKernelGGL(kreduce_stats_kernel, dim3((unsigned)rwk_fused_reduce_stats_blocks(n_graphs)), dim3(kBlock), 0,
+                       (hipStream_t)stream, k_partials, seg_ptr, counts_f32, (long long)n_graphs, (int)c,
+                       (int)stream_len, scale, normalize, (int)rows, k, stats, (unsigned long long *)rng_state,
+                       (unsigned long long *)rng_used);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
+static int head_forward_impl(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
+                             const float *bn_b, float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                             float momentum, float eps, int training, float *stats, int n_stats_ready, const float *w1,
+                             const float *b1, const float *w2, const float *b2, float drop_p, uint64_t *rng_state,
+                             uint64_t *rng_used, float *mean_out, float *invstd_out, float *h1d_out, float *out,
+                             const int64_t *labels, float *loss_partials, rwk_stream_t stream_) {
     if ((labels == nullptr) != (loss_partials == nullptr)) return RWK_E_NULL;
     RWK_REQUIRE_PTR(k);
     RWK_REQUIRE_PTR(bn_w);
@@ -802,17 +1002,18 @@ int rwk_head_forward_loss(const float *k, int64_t g, int64_t c, int64_t p, int64
     hipStream_t stream = (hipStream_t)stream_;
     const int blocks = head_blocks(g);
     const HeadDims dm{(long long)g, (int)c, (int)p, (int)nc};
-    if (training) {
+    if (training && n_stats_ready == 0) {
         hipLaunchKernelGGL(head_stats_kernel, dim3(head_stats_blocks(g)), dim3(kBlock), 0, stream, k, (long long)g, (int)c, stats,
                            drop ? (unsigned long long *)rng_state : nullptr,
                            drop ? (unsigned long long *)rng_used : nullptr);
         RWK_LAUNCH_CHECK();
     }
+    const int n_stats = n_stats_ready > 0 ? n_stats_ready : head_stats_blocks(g);
     const size_t lds = fwd_lds((int)c, (int)p, (int)nc);
     const int rc = allow_lds(head_apply_kernel, lds);
     if (rc != RWK_OK) return rc;
     hipLaunchKernelGGL(head_apply_kernel, dim3(blocks), dim3(kBlock), lds, stream, k, dm, bn_w, bn_b, running_mean,
-                       running_var, (long long *)num_batches_tracked, momentum, eps, training, stats, head_stats_blocks(g), w1, b1,
+                       running_var, (long long *)num_batches_tracked, momentum, eps, training, stats, n_stats, w1, b1,
                        w2, b2, drop_p, (const unsigned long long *)rng_used, mean_out, invstd_out, h1d_out, out,
                        (const long long *)labels, loss_partials);
     RWK_LAUNCH_CHECK();

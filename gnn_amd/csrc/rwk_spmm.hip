@@ -82,6 +82,116 @@ spmm_csr_kernel(const int32_t *__restrict__ crow, const int32_t *__restrict__ co
 }
 
 // ---------------------------------------------------------------------------------------------------
+// What the tile kernel gathers and what it does with a finished row.  PlainOp is the SpMM itself: x rows in,
+// y = A x (+ y) out.  ProjectGradOp lets the last transposed propagation step of the backward pass ride in the
+// launch of the input projection's backward pass, which would otherwise run as a kernel of its own right after it.
+// (The forward counterpart - x1 = A x0 with the neighbours' x0 rows recomputed from their feature rows inside the
+// projection's launch - was built and measured: five sigmoid rows per node instead of one cost more than the
+// launch it saved, 14.0 against 6.0 + 6.2 us on 1024 protein-sized graphs.)
+// ---------------------------------------------------------------------------------------------------
+struct PlainOp {
+    const float *__restrict__ x;
+    float *__restrict__ y;
+    int d, accumulate;
+
+    template <bool ALIGNED>
+    __device__ inline float4 fetch(int c, int sub) const {
+        const float *xr = x + (size_t)c * d;
+        if (ALIGNED) return *reinterpret_cast<const float4 *>(xr + 4 * sub);
+        float t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int b = 4 * sub + j;
+            const float w = xr[b < d ? b : d - 1];
+            t[j] = b < d ? w : 0.f;
+        }
+        return make_float4(t[0], t[1], t[2], t[3]);
+    }
+
+    template <bool ALIGNED>
+    __device__ inline void finish(int /*block*/, int row, int sub, bool has_row, float4 acc, float * /*lds*/) const {
+        if (!has_row) return;
+        float *yr = y + (size_t)row * d;
+        const int b = 4 * sub;
+        if (ALIGNED) {
+            float4 *yp = reinterpret_cast<float4 *>(yr + b);
+            if (accumulate) {
+                const float4 o = *yp;
+                acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+            }
+            *yp = acc;
+        } else {
+            const float a[4] = {acc.x, acc.y, acc.z, acc.w};
+            for (int k = 0; k < 4; ++k)
+                if (b + k < d) yr[b + k] = accumulate ? yr[b + k] + a[k] : a[k];
+        }
+    }
+};
+
+// hidden_dim 4, one lane per row; the matrix is A^T.  The finished row A^T dX_1 completes dX_0, whose only reader
+// is the projection's backward pass (autograd of model.py:43): d_pre = dX_0 x0 (1 - x0), this row's terms of
+// dW = d_pre^T features and db = sum d_pre, added over the workgroup's 256 rows (each wavefront in a fixed
+// butterfly order, then the four wavefront sums in index order) into one partial row [dW (4, f) | db (4)].
+template <int FP>
+struct ProjectGradOp {
+    const float *__restrict__ dx0, *__restrict__ dx1, *__restrict__ x0, *__restrict__ feat, *__restrict__ w;
+    int f;
+    float *__restrict__ partials, *__restrict__ d_feat;
+
+    template <bool ALIGNED>
+    __device__ inline float4 fetch(int c, int /*sub*/) const { return reinterpret_cast<const float4 *>(dx1)[c]; }
+
+    template <bool ALIGNED>
+    __device__ inline void finish(int block, int row, int /*sub*/, bool has_row, float4 acc, float *lds) const {
+        float dpre[4] = {0.f, 0.f, 0.f, 0.f}, fr[FP];
+#pragma unroll
+        for (int k = 0; k < FP; ++k) fr[k] = 0.f;
+        if (has_row) {
+            const float4 g0 = reinterpret_cast<const float4 *>(dx0)[row];
+            const float4 xv = reinterpret_cast<const float4 *>(x0)[row];
+#pragma unroll
+            for (int k = 0; k < FP; ++k)
+                if (k < f) fr[k] = feat[(size_t)row * f + k];
+            // dX_0 = (the fused kernel's own share) + A^T dX_1, as the accumulating SpMM forms it
+            const float gt[4] = {g0.x + acc.x, g0.y + acc.y, g0.z + acc.z, g0.w + acc.w};
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dpre[c] = gt[c] * xs[c] * (1.0f - xs[c]);
+            if (d_feat != nullptr) {
+#pragma unroll
+                for (int k = 0; k < FP; ++k) {
+                    if (k < f) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v = fmaf(dpre[c], w[c * f + k], v);
+                        d_feat[(size_t)row * f + k] = v;
+                    }
+                }
+            }
+        }
+        const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int k = 0; k < FP; ++k) {
+                const float t = rwk_group_sum(dpre[c] * fr[k], 64);
+                if (lane == 0) lds[(c * FP + k) * 4 + wave] = t;
+            }
+            const float t = rwk_group_sum(dpre[c], 64);
+            if (lane == 0) lds[(4 * FP + c) * 4 + wave] = t;
+        }
+        __syncthreads();
+        const int n_out = 4 * f + 4;
+        float *out = partials + (size_t)block * n_out;
+        for (int o = tid; o < n_out; o += kBlock) {
+            const int r = o < 4 * f ? (o / f) * FP + o % f : 4 * FP + (o - 4 * f);
+            const float *p = lds + r * 4;
+            out[o] = ((p[0] + p[1]) + p[2]) + p[3];
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
 // Tile kernel for sparse rows (mean degree well below 64): a workgroup owns 256/VEC consecutive rows,
 // hence one contiguous range of stored entries.  Phase 1 walks that range entry-parallel: column and
 // value are read coalesced, each entry's x row is gathered by VEC lanes (every gather of a pass is in
@@ -102,10 +212,10 @@ constexpr int kColBlock = 256;
 
 // bid / nblocks: this workgroup's index among the SpMM workgroups of the launch (they come first in a merged launch,
 // so the dispatch order, and with it the XCD a workgroup lands on, is that of a stand-alone launch)
-template <int VEC, bool ALIGNED, typename COLT, bool UNIT>
+template <int VEC, bool ALIGNED, typename COLT, bool UNIT, typename OP>
 __device__ inline void spmm_tile_body(int bid, int nblocks, const int32_t *__restrict__ crow,
-                                      const COLT *__restrict__ col, const float *__restrict__ val, int n, int d,
-                                      const float *__restrict__ x, float *__restrict__ y, int accumulate) {
+                                      const COLT *__restrict__ col, const float *__restrict__ val, int n,
+                                      const OP &op) {
     constexpr int RPW = kBlock / VEC;                   // rows per workgroup = entry slots per pass
     constexpr int ET = kTileBytes / (16 * VEC);         // entries per LDS tile
     constexpr int PASSES = ET / RPW;
@@ -154,21 +264,7 @@ __device__ inline void spmm_tile_body(int bid, int nblocks, const int32_t *__res
             }
             float4 xv[GP];
 #pragma unroll
-            for (int k = 0; k < GP; ++k) {
-                const float *xr = x + (size_t)c[k] * d;
-                if (ALIGNED) {
-                    xv[k] = *reinterpret_cast<const float4 *>(xr + 4 * sub);
-                } else {
-                    float t[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int b = 4 * sub + j;
-                        const float w = xr[b < d ? b : d - 1];
-                        t[j] = b < d ? w : 0.f;
-                    }
-                    xv[k] = make_float4(t[0], t[1], t[2], t[3]);
-                }
-            }
+            for (int k = 0; k < GP; ++k) xv[k] = op.template fetch<ALIGNED>(c[k], sub);
 #pragma unroll
             for (int k = 0; k < GP; ++k) {
                 const int e = cb + slot + (g + k) * RPW;
@@ -235,28 +331,15 @@ __device__ inline void spmm_tile_body(int bid, int nblocks, const int32_t *__res
         __syncthreads();
     }
 
-    if (!has_row) return;
-    float *yr = y + (size_t)(r0 + slot) * d;
-    const int b = 4 * sub;
-    if (ALIGNED) {
-        float4 *yp = reinterpret_cast<float4 *>(yr + b);
-        if (accumulate) {
-            const float4 o = *yp;
-            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
-        }
-        *yp = acc;
-    } else {
-        const float a[4] = {acc.x, acc.y, acc.z, acc.w};
-        for (int k = 0; k < 4; ++k)
-            if (b + k < d) yr[b + k] = accumulate ? yr[b + k] + a[k] : a[k];
-    }
+    // s_red is free again: every use above is followed by a workgroup barrier
+    op.template finish<ALIGNED>(lb, r0 + slot, sub, has_row, acc, reinterpret_cast<float *>(s_red));
 }
 
 template <int VEC, bool ALIGNED, typename COLT, bool UNIT>
 __global__ void __launch_bounds__(kBlock)
 spmm_tile_kernel(const int32_t *__restrict__ crow, const COLT *__restrict__ col, const float *__restrict__ val,
                  int n, int d, const float *__restrict__ x, float *__restrict__ y, int accumulate) {
-    spmm_tile_body<VEC, ALIGNED, COLT, UNIT>(blockIdx.x, gridDim.x, crow, col, val, n, d, x, y, accumulate);
+    spmm_tile_body<VEC, ALIGNED, COLT, UNIT>(blockIdx.x, gridDim.x, crow, col, val, n, PlainOp{x, y, d, accumulate});
 }
 
 // The tile SpMM and the first level of an independent row reduction in one launch: workgroups [0, spmm_blocks)
@@ -268,7 +351,24 @@ spmm_tile_reduce_kernel(const int32_t *__restrict__ crow, const COLT *__restrict
                         int spmm_blocks, const float *__restrict__ red_in, long long red_p, long long red_v,
                         int red_rows_per_block, int red_bx, float *__restrict__ red_out) {
     if ((int)blockIdx.x < spmm_blocks) {
-        spmm_tile_body<VEC, ALIGNED, COLT, UNIT>(blockIdx.x, spmm_blocks, crow, col, val, n, d, x, y, accumulate);
+        spmm_tile_body<VEC, ALIGNED, COLT, UNIT>(blockIdx.x, spmm_blocks, crow, col, val, n,
+                                                 PlainOp{x, y, d, accumulate});
+    } else {
+        const int r = (int)blockIdx.x - spmm_blocks;
+        reduce_rows_level1_body(r % red_bx, r / red_bx, red_in, red_p, red_v, red_rows_per_block, red_out);
+    }
+}
+
+// The last transposed propagation step inside the projection's backward pass (tile body with ProjectGradOp) and the
+// first level of the dZ partial-sum reduction in one launch.
+template <typename COLT, bool UNIT, int FP>
+__global__ void __launch_bounds__(kBlock)
+spmm_project_backward_kernel(const int32_t *__restrict__ crow, const COLT *__restrict__ col,
+                             const float *__restrict__ val, int n, int spmm_blocks, ProjectGradOp<FP> op,
+                             const float *__restrict__ red_in, long long red_p, long long red_v, int red_rows_per_block,
+                             int red_bx, float *__restrict__ red_out) {
+    if ((int)blockIdx.x < spmm_blocks) {
+        spmm_tile_body<1, true, COLT, UNIT>(blockIdx.x, spmm_blocks, crow, col, val, n, op);
     } else {
         const int r = (int)blockIdx.x - spmm_blocks;
         reduce_rows_level1_body(r % red_bx, r / red_bx, red_in, red_p, red_v, red_rows_per_block, red_out);
@@ -441,3 +541,62 @@ extern "C" int rwk_spmm_tile_reduce_rows(const int32_t *crow, const int32_t *col
         return launch_tile_by_width<int16_t>(crow, col16, val, n, d, x, y, accumulate, (hipStream_t)stream, &job);
     return launch_tile_by_width<int32_t>(crow, col, val, n, d, x, y, accumulate, (hipStream_t)stream, &job);
 }
+
+// FP = padded input width the projection bodies are instantiated for
+#define RWK_BY_FP(f, M)            \
+    do {                           \
+        if ((f) == 1) { M(1); }    \
+        else if ((f) <= 4) { M(4); } \
+        else { M(16); }            \
+    } while (0)
+
+extern "C" int64_t rwk_spmm_project_backward_blocks(int64_t n) { return n > 0 ? rwk_ceil_div(n, kBlock) : 0; }
+
+extern "C" int rwk_spmm_project_backward(const float *dx0, const float *dx1, const float *x0, const float *features,
+                                         const float *weight, int64_t n, int64_t f, const int32_t *crow_t,
+                                         const int32_t *col_t, const int16_t *col16_t, const float *val_t,
+                                         float *partials, float *d_features, const float *red_in, int64_t red_p,
+                                         int64_t red_v, float *red_out32, rwk_stream_t stream_) {
+    RWK_REQUIRE_PTR(dx0);
+    RWK_REQUIRE_PTR(dx1);
+    RWK_REQUIRE_PTR(x0);
+    RWK_REQUIRE_PTR(features);
+    RWK_REQUIRE_PTR(weight);
+    RWK_REQUIRE_PTR(crow_t);
+    RWK_REQUIRE_PTR(partials);
+    if (col_t == nullptr && col16_t == nullptr) return RWK_E_NULL;
+    if (n <= 0 || f <= 0 || n >= 0x7FFFFFFFll / 4) return RWK_E_SIZE;
+    if (f > 16) return RWK_E_UNSUPPORTED;
+    if ((((uintptr_t)dx0 | (uintptr_t)dx1 | (uintptr_t)x0) & 15u) != 0) return RWK_E_ALIGN;
+    const int spmm_blocks = (int)rwk_ceil_div(n, kBlock);
+    int red_bx = 0, rows_per_block = 0;
+    if (red_in != nullptr) {
+        RWK_REQUIRE_PTR(red_out32);
+        if (red_p <= kReduceMaxFinalRows || red_v <= 0 || red_v >= 0x7FFFFFFFll * 64) return RWK_E_SIZE;
+        red_bx = (int)rwk_ceil_div(red_v, 64);
+        rows_per_block = (int)rwk_ceil_div(red_p, kReduceMaxFinalRows);
+    }
+    const dim3 grid((unsigned)(spmm_blocks + red_bx * kReduceMaxFinalRows));
+    hipStream_t stream = (hipStream_t)stream_;
+#define RWK_SPB_K(COLT, COLP, UN, FP)                                                                                \
+    hipLaunchKernelGGL((spmm_project_backward_kernel<COLT, UN, FP>), grid, dim3(kBlock), 0, stream, crow_t, COLP, val_t, \
+                       (int)n, spmm_blocks,                                                                           \
+                       (ProjectGradOp<FP>{dx0, dx1, x0, features, weight, (int)f, partials, d_features}), red_in,     \
+                       (long long)red_p, (long long)red_v, rows_per_block, red_bx > 0 ? red_bx : 1, red_out32)
+#define RWK_SPB(FP)                                                              \
+    do {                                                                         \
+        if (col16_t != nullptr) {                                                \
+            if (val_t == nullptr) RWK_SPB_K(int16_t, col16_t, true, FP);         \
+            else RWK_SPB_K(int16_t, col16_t, false, FP);                         \
+        } else {                                                                 \
+            if (val_t == nullptr) RWK_SPB_K(int32_t, col_t, true, FP);           \
+            else RWK_SPB_K(int32_t, col_t, false, FP);                           \
+        }                                                                        \
+    } while (0)
+    RWK_BY_FP(f, RWK_SPB);
+#undef RWK_SPB
+#undef RWK_SPB_K
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+#undef RWK_BY_FP

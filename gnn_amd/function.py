@@ -17,7 +17,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from .structure import GraphStructure
+from .structure import GraphStructure, use_tile_kernel
 
 __all__ = ["rw_kernel_layer", "rw_kernel_layer_projected", "choose_stream_len", "FUSED_PROJECTION_MAX_INPUT_DIM"]
 
@@ -25,6 +25,11 @@ FUSED_PROJECTION_MAX_INPUT_DIM = 16
 #: launch the hidden-graph kernels together with the projection kernels they are independent of (one launch
 #: instead of two, forward and backward); False keeps the stand-alone launches (tests compare the two)
 MERGED_LAUNCHES = True
+#: do the last transposed propagation step inside the projection's backward launch, the hidden-graph backward
+#: beside the projection-gradient sum (hidden_dim 4, narrow inputs, at least two steps, a matrix the tile SpMM
+#: kernel serves), and the batch statistics of the head inside the K reduction; False keeps the stand-alone
+#: launches (tests compare the two)
+FUSED_STEP_LAUNCHES = True
 
 def choose_stream_len(n_nodes: int, hidden_dim: int, n_hidden: int, size_hidden: int, max_step: int,
                       backward: bool = False) -> int:
@@ -50,7 +55,7 @@ class _RWKernelLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, inp, fc_weight, fc_bias, adj_hidden, features_hidden, st: GraphStructure, max_step: int,
-                normalize: bool, drop_p: float, rng_state):
+                normalize: bool, drop_p: float, rng_state, handoff=None):
         lib = _lib.load()
         if not inp.is_cuda:
             raise RuntimeError("gnn_amd runs on HIP devices only (no CPU fallback)")
@@ -76,7 +81,11 @@ class _RWKernelLayer(torch.autograd.Function):
             ah = torch.empty((n_hidden, s, s), dtype=torch.float32, device=dev)
             rng_used = torch.empty(2, dtype=torch.int64, device=dev) if drop else None
             rng_in = _lib.ptr(rng_state) if drop else None
-            if projected and d == 4 and MERGED_LAUNCHES:                         # model.py:39-43,56 in one launch
+            f_in = inp_c.shape[1]
+            fuse_step = (projected and d == 4 and steps >= 2 and MERGED_LAUNCHES and FUSED_STEP_LAUNCHES
+                         and 4 * f_in + 4 <= 64 and st.nnz > 0
+                         and use_tile_kernel(n, st.nnz, st.csr_t.max_degree, 4))
+            if projected and d == 4 and MERGED_LAUNCHES:                       # model.py:39-43,56 in one launch
                 w_c = fc_weight.detach().contiguous()
                 _lib.check(lib.rwk_project_hidden_forward(
                     inp_c.data_ptr(), w_c.data_ptr(), fc_bias.detach().contiguous().data_ptr(), n, inp_c.shape[1], d,
@@ -102,11 +111,25 @@ class _RWKernelLayer(torch.autograd.Function):
                                              n, d, n_hidden, s, steps, stream_len, drop, _lib.ptr(rng_used),
                                              k_partials.data_ptr(), stream), "rwk_fused_forward")
             k = torch.empty((g, steps * n_hidden), dtype=torch.float32, device=dev)
-            _lib.check(lib.rwk_fused_reduce(k_partials.data_ptr(), st.seg_ptr.data_ptr(),
-                                            st.counts_f32.data_ptr(), g, n_hidden, steps, stream_len, drop,
-                                            int(bool(normalize)), k.data_ptr(), stream), "rwk_fused_reduce")
+            if handoff is not None and FUSED_STEP_LAUNCHES and steps * n_hidden <= 256:
+                # the head's batch statistics (and its draw of the generator state) ride in the K reduction
+                head_drop = bool(handoff.get("head_drop")) and rng_state is not None
+                stats = torch.empty(lib.rwk_head_stats_size(g, steps * n_hidden), dtype=torch.float32, device=dev)
+                rng_head = torch.empty(2, dtype=torch.int64, device=dev) if head_drop else None
+                _lib.check(lib.rwk_fused_reduce_stats(
+                    k_partials.data_ptr(), st.seg_ptr.data_ptr(), st.counts_f32.data_ptr(), g, n_hidden, steps,
+                    stream_len, drop, int(bool(normalize)), k.data_ptr(), stats.data_ptr(),
+                    _lib.ptr(rng_state) if head_drop else None, _lib.ptr(rng_head), stream), "rwk_fused_reduce_stats")
+                handoff["stats"] = stats
+                handoff["n_stats"] = int(lib.rwk_fused_reduce_stats_blocks(g))
+                handoff["rng_used"] = rng_head
+            else:
+                _lib.check(lib.rwk_fused_reduce(k_partials.data_ptr(), st.seg_ptr.data_ptr(),
+                                                st.counts_f32.data_ptr(), g, n_hidden, steps, stream_len, drop,
+                                                int(bool(normalize)), k.data_ptr(), stream), "rwk_fused_reduce")
         ctx.st = st
         ctx.cfg = (steps, bool(normalize), drop, projected)
+        ctx.fuse_step = fuse_step
         ctx.save_for_backward(xs, z, ah, adj_hidden_c, rng_used, inp_c if projected else None, w_c)
         return k
 
@@ -143,18 +166,40 @@ class _RWKernelLayer(torch.autograd.Function):
                 dz_rows = lib.rwk_reduce_rows_level1(n_part)
                 dz = torch.empty((dz_rows, dz_partials.shape[1]), dtype=torch.float32, device=dev)
                 job = (dz_partials, dz)
-            for i in range(steps - 1, 0, -1):                                   # dX[i-1] += A^T dX[i]
+            last = 1 if ctx.fuse_step else 0                                    # the fused launch does step 1 -> 0
+            for i in range(steps - 1, last, -1):                                # dX[i-1] += A^T dX[i]
                 st.spmm(dx[i], dx[i - 1], transpose=True, accumulate=True,
                         reduce_job=job if MERGED_LAUNCHES else None)
                 if MERGED_LAUNCHES:
                     job = None
-            if job is not None:
-                _lib.check(lib.rwk_reduce_rows_to32(dz_partials.data_ptr(), n_part, dz_partials.shape[1],
-                                                    dz.data_ptr(), stream), "rwk_reduce_rows_to32")
             d_adj = torch.empty_like(adj_hidden_c)
             d_feat = torch.empty((n_hidden, s, d), dtype=torch.float32, device=dev)
             x0 = xs[0]
             d_w = d_b = None
+            if ctx.fuse_step:
+                f = feats.shape[1]
+                csr_t = st.csr_t
+                blocks = lib.rwk_spmm_project_backward_blocks(n)
+                partials = torch.empty((blocks, d * f + d), dtype=torch.float32, device=dev)
+                d_inp = torch.empty_like(feats) if ctx.needs_input_grad[0] else None
+                red_in, red_out = job if job is not None else (None, None)
+                _lib.check(lib.rwk_spmm_project_backward(
+                    dx[0].data_ptr(), dx[1].data_ptr(), x0.data_ptr(), feats.data_ptr(), w_c.data_ptr(), n, f,
+                    csr_t.crow.data_ptr(), _lib.ptr(csr_t.col), _lib.ptr(csr_t.col16),
+                    None if (csr_t.col16 is not None and csr_t.unit_values) else _lib.ptr(csr_t.val),
+                    partials.data_ptr(), _lib.ptr(d_inp), _lib.ptr(red_in), red_in.shape[0] if job else 0,
+                    red_in.shape[1] if job else 0, _lib.ptr(red_out), stream), "rwk_spmm_project_backward")
+                wb = torch.empty(d * f + d, dtype=torch.float32, device=dev)
+                _lib.check(lib.rwk_hidden_backward_reduce(
+                    _lib.ptr(adj_hidden_c), ah.data_ptr(), z.data_ptr(), dz.data_ptr(), dz_rows, n_hidden, s, d, steps,
+                    _lib.ptr(d_adj), d_feat.data_ptr(), partials.data_ptr(), blocks, d * f + d, wb.data_ptr(), stream),
+                    "rwk_hidden_backward_reduce")
+                d_w = wb[:d * f].view(d, f)
+                d_b = wb[d * f:]
+                return d_inp, d_w, d_b, d_adj, d_feat, None, None, None, None, None, None
+            if job is not None:
+                _lib.check(lib.rwk_reduce_rows_to32(dz_partials.data_ptr(), n_part, dz_partials.shape[1],
+                                                    dz.data_ptr(), stream), "rwk_reduce_rows_to32")
             merged = projected and MERGED_LAUNCHES
             if not merged:
                 _lib.check(lib.rwk_hidden_backward(_lib.ptr(adj_hidden_c), ah.data_ptr(), z.data_ptr(),
@@ -183,20 +228,24 @@ class _RWKernelLayer(torch.autograd.Function):
                 d_inp = dx[0] * x0 * (1.0 - x0)                                  # sigmoid'
         # with a single step adj_hidden never enters the forward pass: the reference leaves its
         # .grad at None, and so do we
-        return d_inp, d_w, d_b, (d_adj if steps > 1 else None), d_feat, None, None, None, None, None
+        return d_inp, d_w, d_b, (d_adj if steps > 1 else None), d_feat, None, None, None, None, None, None
 
 
 def rw_kernel_layer(pre, adj_hidden, features_hidden, structure: GraphStructure, max_step: int,
-                    normalize: bool, drop_p: float = 0.0, rng_state=None):
-    """(G, max_step*H) random-walk-kernel features; ``pre`` is ``fc(features)`` BEFORE the sigmoid."""
+                    normalize: bool, drop_p: float = 0.0, rng_state=None, handoff=None):
+    """(G, max_step*H) random-walk-kernel features; ``pre`` is ``fc(features)`` BEFORE the sigmoid.
+
+    ``handoff``: a dict ``{"head_drop": bool}`` from a caller that feeds K to the fused head in training mode: the
+    K reduction then also leaves the head's batch-statistics partials (``handoff["stats"]``, ``["n_stats"]``) and
+    draws the head's dropout generator state (``["rng_used"]``), which saves the head its statistics launch."""
     return _RWKernelLayer.apply(pre, None, None, adj_hidden, features_hidden, structure, max_step, normalize,
-                                drop_p, rng_state)
+                                drop_p, rng_state, handoff)
 
 
 def rw_kernel_layer_projected(features, fc_weight, fc_bias, adj_hidden, features_hidden,
                               structure: GraphStructure, max_step: int, normalize: bool, drop_p: float = 0.0,
-                              rng_state=None):
+                              rng_state=None, handoff=None):
     """Same, with the input projection ``sigmoid(features @ fc_weight.T + fc_bias)`` fused in
     (``features.shape[1] <= FUSED_PROJECTION_MAX_INPUT_DIM``)."""
     return _RWKernelLayer.apply(features, fc_weight, fc_bias, adj_hidden, features_hidden, structure, max_step,
-                                normalize, drop_p, rng_state)
+                                normalize, drop_p, rng_state, handoff)

@@ -18,10 +18,37 @@ def head_supported(n_graphs: int, n_features: int, penultimate_dim: int, n_class
     return bool(_lib.load().rwk_head_supported(n_graphs, n_features, penultimate_dim, n_classes))
 
 
+def _launch_forward(lib, kc, g, c, p, nc, bn_wc, bn_bc, running_mean, running_var, num_batches_tracked, momentum, eps,
+                    training, w1c, b1c, w2c, b2c, drop, rng_state, mean, invstd, h1d, out, labels, loss_partials,
+                    handoff, stream):
+    """One head forward.  ``handoff`` (from the random-walk layer's K reduction, see ``rw_kernel_layer``) carries the
+    batch-statistics partials of ``kc`` and the drawn generator state: the statistics launch is then skipped."""
+    dev = kc.device
+    if training and handoff is not None and handoff.get("stats") is not None:
+        rng_used = handoff.get("rng_used") if drop else None
+        if drop and rng_used is None:
+            raise RuntimeError("the statistics handoff does not carry the head's generator state")
+        _lib.check(lib.rwk_head_apply_loss(
+            kc.data_ptr(), g, c, p, nc, bn_wc.data_ptr(), bn_bc.data_ptr(), running_mean.data_ptr(),
+            running_var.data_ptr(), _lib.ptr(num_batches_tracked), float(momentum), float(eps),
+            handoff["stats"].data_ptr(), int(handoff["n_stats"]), w1c.data_ptr(), b1c.data_ptr(), w2c.data_ptr(),
+            b2c.data_ptr(), drop, _lib.ptr(rng_used), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(h1d), out.data_ptr(),
+            _lib.ptr(labels), _lib.ptr(loss_partials), stream), "rwk_head_apply_loss")
+        return
+    stats = torch.empty(lib.rwk_head_stats_size(g, c), dtype=torch.float32, device=dev) if training else None
+    rng_used = torch.empty(2, dtype=torch.int64, device=dev) if drop else None
+    _lib.check(lib.rwk_head_forward_loss(
+        kc.data_ptr(), g, c, p, nc, bn_wc.data_ptr(), bn_bc.data_ptr(), running_mean.data_ptr(),
+        running_var.data_ptr(), _lib.ptr(num_batches_tracked), float(momentum), float(eps), int(training),
+        _lib.ptr(stats), w1c.data_ptr(), b1c.data_ptr(), w2c.data_ptr(), b2c.data_ptr(), drop,
+        _lib.ptr(rng_state) if drop else None, _lib.ptr(rng_used), _lib.ptr(mean), _lib.ptr(invstd),
+        _lib.ptr(h1d), out.data_ptr(), _lib.ptr(labels), _lib.ptr(loss_partials), stream), "rwk_head_forward_loss")
+
+
 class _FusedHead(torch.autograd.Function):
     @staticmethod
     def forward(ctx, k, bn_w, bn_b, w1, b1, w2, b2, running_mean, running_var, num_batches_tracked, momentum, eps,
-                training, drop_p, rng_state):
+                training, drop_p, rng_state, handoff=None):
         lib = _lib.load()
         if not k.is_cuda:
             raise RuntimeError("gnn_amd runs on HIP devices only (no CPU fallback)")
@@ -40,18 +67,13 @@ class _FusedHead(torch.autograd.Function):
             tensors = [t.detach().contiguous() for t in (bn_w, bn_b, w1, b1, w2, b2)]
             bn_wc, bn_bc, w1c, b1c, w2c, b2c = tensors
             out = torch.empty((g, nc), dtype=torch.float32, device=dev)
-            stats = torch.empty(lib.rwk_head_stats_size(g, c), dtype=torch.float32, device=dev) if training else None
             keep = training or needs_grad
             mean = torch.empty(c, dtype=torch.float32, device=dev) if keep else None
             invstd = torch.empty(c, dtype=torch.float32, device=dev) if keep else None
             h1d = torch.empty((g, p), dtype=torch.float32, device=dev) if needs_grad else None
-            rng_used = torch.empty(2, dtype=torch.int64, device=dev) if drop else None
-            _lib.check(lib.rwk_head_forward(
-                kc.data_ptr(), g, c, p, nc, bn_wc.data_ptr(), bn_bc.data_ptr(), running_mean.data_ptr(),
-                running_var.data_ptr(), _lib.ptr(num_batches_tracked), float(momentum), float(eps), int(training),
-                _lib.ptr(stats), w1c.data_ptr(), b1c.data_ptr(), w2c.data_ptr(), b2c.data_ptr(), drop,
-                _lib.ptr(rng_state) if drop else None, _lib.ptr(rng_used), _lib.ptr(mean), _lib.ptr(invstd),
-                _lib.ptr(h1d), out.data_ptr(), stream), "rwk_head_forward")
+            _launch_forward(lib, kc, g, c, p, nc, bn_wc, bn_bc, running_mean, running_var, num_batches_tracked,
+                            momentum, eps, training, w1c, b1c, w2c, b2c, drop, rng_state, mean, invstd, h1d, out,
+                            None, None, handoff, stream)
         ctx.cfg = (training, drop)
         ctx.save_for_backward(kc, bn_wc, bn_bc, w1c, w2c, mean, invstd, h1d, out)
         return out
@@ -86,7 +108,7 @@ class _FusedHead(torch.autograd.Function):
         d_b1 = grads[o:o + p]; o += p
         d_bn_w = grads[o:o + c]; o += c
         d_bn_b = grads[o:o + c]
-        return (d_k, d_bn_w, d_bn_b, d_w1, d_b1, d_w2, d_b2) + (None,) * 8
+        return (d_k, d_bn_w, d_bn_b, d_w1, d_b1, d_w2, d_b2) + (None,) * 9
 
 
 class _FusedHeadLoss(torch.autograd.Function):
@@ -97,7 +119,7 @@ class _FusedHeadLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, k, labels, bn_w, bn_b, w1, b1, w2, b2, running_mean, running_var, num_batches_tracked, momentum,
-                eps, training, drop_p, rng_state, grad_mode):
+                eps, training, drop_p, rng_state, grad_mode, handoff=None):
         lib = _lib.load()
         if not k.is_cuda:
             raise RuntimeError("gnn_amd runs on HIP devices only (no CPU fallback)")
@@ -121,21 +143,15 @@ class _FusedHeadLoss(torch.autograd.Function):
             bn_wc, bn_bc, w1c, b1c, w2c, b2c = [t.detach().contiguous() for t in (bn_w, bn_b, w1, b1, w2, b2)]
             out = torch.empty((g, nc), dtype=torch.float32, device=dev)
             loss = torch.empty((), dtype=torch.float32, device=dev)
-            stats = torch.empty(lib.rwk_head_stats_size(g, c), dtype=torch.float32, device=dev) if training else None
             keep = training or needs_grad
             mean = torch.empty(c, dtype=torch.float32, device=dev) if keep else None
             invstd = torch.empty(c, dtype=torch.float32, device=dev) if keep else None
             h1d = torch.empty((g, p), dtype=torch.float32, device=dev) if needs_grad else None
-            rng_used = torch.empty(2, dtype=torch.int64, device=dev) if drop else None
             loss_partials = torch.empty(lib.rwk_head_n_blocks(g), dtype=torch.float32, device=dev) if needs_grad \
                 else None
-            _lib.check(lib.rwk_head_forward_loss(
-                kc.data_ptr(), g, c, p, nc, bn_wc.data_ptr(), bn_bc.data_ptr(), running_mean.data_ptr(),
-                running_var.data_ptr(), _lib.ptr(num_batches_tracked), float(momentum), float(eps), int(training),
-                _lib.ptr(stats), w1c.data_ptr(), b1c.data_ptr(), w2c.data_ptr(), b2c.data_ptr(), drop,
-                _lib.ptr(rng_state) if drop else None, _lib.ptr(rng_used), _lib.ptr(mean), _lib.ptr(invstd),
-                _lib.ptr(h1d), out.data_ptr(), yc.data_ptr() if needs_grad else None, _lib.ptr(loss_partials),
-                stream), "rwk_head_forward_loss")
+            _launch_forward(lib, kc, g, c, p, nc, bn_wc, bn_bc, running_mean, running_var, num_batches_tracked,
+                            momentum, eps, training, w1c, b1c, w2c, b2c, drop, rng_state, mean, invstd, h1d, out,
+                            yc if needs_grad else None, loss_partials, handoff, stream)
             if not needs_grad:
                 _lib.check(lib.rwk_cross_entropy_forward(out.data_ptr(), yc.data_ptr(), g, nc, loss.data_ptr(),
                                                          stream), "rwk_cross_entropy_forward")
@@ -174,20 +190,21 @@ class _FusedHeadLoss(torch.autograd.Function):
         d_b1 = grads[o:o + p]; o += p
         d_bn_w = grads[o:o + c]; o += c
         d_bn_b = grads[o:o + c]
-        return (d_k, None, d_bn_w, d_bn_b, d_w1, d_b1, d_w2, d_b2) + (None,) * 9
+        return (d_k, None, d_bn_w, d_bn_b, d_w1, d_b1, d_w2, d_b2) + (None,) * 10
 
 
-def fused_head_loss(k, labels, bn, fc1, fc2, drop_p: float, training: bool, rng_state=None):
+def fused_head_loss(k, labels, bn, fc1, fc2, drop_p: float, training: bool, rng_state=None, handoff=None):
     """``out = fused_head(...)`` and ``loss = F.cross_entropy(out, labels)`` in the head's own launches; returns
     ``(out, loss)`` with ``out`` detached.  With gradients enabled the value of ``loss`` is complete once
     ``loss.backward()`` has run (the backward launch finishes the sum): read it after the step."""
     return _FusedHeadLoss.apply(k, labels, bn.weight, bn.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias,
                                 bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps,
-                                training, drop_p, rng_state, torch.is_grad_enabled())
+                                training, drop_p, rng_state, torch.is_grad_enabled(), handoff)
 
 
-def fused_head(k, bn, fc1, fc2, drop_p: float, training: bool, rng_state=None):
+def fused_head(k, bn, fc1, fc2, drop_p: float, training: bool, rng_state=None, handoff=None):
     """``log_softmax(fc2(dropout(relu(fc1(bn(k))))))`` with ``bn`` an ``nn.BatchNorm1d`` (affine, tracking running
     statistics, float momentum) and ``fc1``/``fc2`` ``nn.Linear`` with bias."""
     return _FusedHead.apply(k, bn.weight, bn.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, bn.running_mean,
-                            bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps, training, drop_p, rng_state)
+                            bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps, training, drop_p, rng_state,
+                            handoff)

@@ -69,16 +69,25 @@ class RW_NN(nn.Module):
             pre = self.fc(features)
             k = pre.new_zeros(structure.n_graphs, self.hidden_graphs * self.max_step)
             k = k + 0.0 * (pre.sum() + self.features_hidden.sum() + self.adj_hidden.sum())
+            handoff = None
         else:
-            k = self._rw(features, structure, drop)
-        return self._head(k, drop)
+            handoff = self._head_handoff(structure, drop)
+            k = self._rw(features, structure, drop, handoff)
+        return self._head(k, drop, handoff)
 
-    def _head(self, k, drop):
+    def _head_handoff(self, structure, drop):
+        """Training mode with the fused head: ask the random-walk layer's K reduction for the head's batch
+        statistics (one launch less), see :func:`gnn_amd.function.rw_kernel_layer`."""
+        if not (self.training and self._head_fusable(structure.n_graphs, self.hidden_graphs * self.max_step, drop)):
+            return None
+        return {"head_drop": drop > 0.0}
+
+    def _head(self, k, drop, handoff=None):
         if self._use_fused_head(k, drop):
             if drop > 0.0 and not self._rng_seeded:
                 self._seed_from_torch()
             return fused_head(k, self.bn, self.fc1, self.fc2, drop, self.training,
-                              self._rng_state if drop > 0.0 else None)
+                              self._rng_state if drop > 0.0 else None, handoff)
         out = self.bn(k)
         out = self.relu(self.fc1(out))
         out = self.dropout(out)
@@ -94,36 +103,41 @@ class RW_NN(nn.Module):
         p = float(self.dropout.p)
         drop = p if self.training else 0.0
         if drop < 1.0 and torch.is_grad_enabled():
-            k = self._rw(features, structure, drop)
+            handoff = self._head_handoff(structure, drop)
+            k = self._rw(features, structure, drop, handoff)
             if self._use_fused_head(k, drop) and y.dtype == torch.int64 and y.dim() == 1:
                 if drop > 0.0 and not self._rng_seeded:
                     self._seed_from_torch()
                 return fused_head_loss(k, y, self.bn, self.fc1, self.fc2, drop, self.training,
-                                       self._rng_state if drop > 0.0 else None)
-            out = self._head(k, drop)
+                                       self._rng_state if drop > 0.0 else None, handoff)
+            out = self._head(k, drop, handoff)
         else:
             out = self.forward(adj, features, graph_indicator)
         return out, cross_entropy(out, y)
 
     def _use_fused_head(self, k, drop):
+        return k.is_cuda and self._head_fusable(k.shape[0], k.shape[1], drop)
+
+    def _head_fusable(self, n_graphs, n_features, drop):
         bn = self.bn
-        return (self.fused_head and k.is_cuda and drop < 1.0 and bn.affine and bn.track_running_stats
+        return (self.fused_head and drop < 1.0 and bn.affine and bn.track_running_stats
                 and bn.momentum is not None and self.fc1.bias is not None and self.fc2.bias is not None
-                and head_supported(k.shape[0], k.shape[1], self.fc1.out_features, self.fc2.out_features))
+                and n_features == bn.num_features
+                and head_supported(n_graphs, n_features, self.fc1.out_features, self.fc2.out_features))
 
     def _seed_from_torch(self):
         self.seed_dropout(int(torch.randint(0, 2 ** 62, (1,)).item()))
 
-    def _rw(self, features, structure, drop):
+    def _rw(self, features, structure, drop, handoff=None):
         if drop > 0.0 and not self._rng_seeded:
             self._seed_from_torch()
         rng = self._rng_state if drop > 0.0 else None
         if features.shape[1] <= FUSED_PROJECTION_MAX_INPUT_DIM:
             return rw_kernel_layer_projected(features, self.fc.weight, self.fc.bias, self.adj_hidden,
                                              self.features_hidden, structure, self.max_step,
-                                             bool(self.normalize), drop, rng)
+                                             bool(self.normalize), drop, rng, handoff)
         return rw_kernel_layer(self.fc(features), self.adj_hidden, self.features_hidden, structure,
-                               self.max_step, bool(self.normalize), drop, rng)
+                               self.max_step, bool(self.normalize), drop, rng, handoff)
 
     def rw_features(self, adj, features, graph_indicator):
         """The (G, max_step*H) input of ``bn`` (model.py:67), for tests and benchmarks."""

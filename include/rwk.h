@@ -288,6 +288,24 @@ int rwk_head_backward_loss(const float *k, int64_t g, int64_t c, int64_t p, int6
                            float *d_k, const int64_t *labels, const float *d_loss, const float *loss_partials,
                            float *loss, rwk_stream_t stream);
 
+/* rwk_fused_reduce (model.py:60-64,67) and the batch statistics of the K it writes (first half of model.py:68) in one
+ * launch: stats receives rwk_fused_reduce_stats_blocks(g) block partials {count, mean[C], M2[C]}, C = h * max_step
+ * <= 256, each over rwk_fused_reduce_stats_rows(g) consecutive rows (room for them: rwk_head_stats_size(g, C)
+ * floats); rng_state / rng_used not NULL: the head's dropout generator state is drawn and advanced, as the
+ * statistics launch of rwk_head_forward does.  rwk_head_apply_loss is rwk_head_forward_loss in training mode without
+ * its statistics launch, on such partials. */
+int64_t rwk_fused_reduce_stats_rows(int64_t g);
+int64_t rwk_fused_reduce_stats_blocks(int64_t g);
+int rwk_fused_reduce_stats(const float *k_partials, const int32_t *seg_ptr, const float *counts_f32, int64_t n_graphs,
+                           int64_t h, int64_t max_step, int64_t stream_len, float drop_p, int normalize, float *k,
+                           float *stats, uint64_t *rng_state, uint64_t *rng_used, rwk_stream_t stream);
+int rwk_head_apply_loss(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
+                        const float *bn_b, float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                        float momentum, float eps, const float *stats, int64_t n_stats, const float *w1,
+                        const float *b1, const float *w2, const float *b2, float drop_p, const uint64_t *rng_used,
+                        float *mean_out, float *invstd_out, float *h1d_out, float *out, const int64_t *labels,
+                        float *loss_partials, rwk_stream_t stream);
+
 /* Mean cross-entropy of (g, nc) scores against int64 labels in [0, nc): F.cross_entropy with its
  * default arguments, as rwgnn2/main.py:85,92 applies it to the model's output.  loss: device
  * float[1].  Backward: d_scores = d_loss[0] / g * (softmax(scores) - onehot(labels)).
@@ -343,6 +361,30 @@ int rwk_project_hidden_backward(const float *dx0, const float *x0, const float *
                                 const float *z, const float *dz_partials, int64_t n_partials, int64_t h,
                                 int64_t s, int64_t max_step, float *d_adj_hidden,
                                 float *d_features_hidden, rwk_stream_t stream);
+
+/* Launches of the backward pass that do the work of two neighbouring kernels of the chain (hidden_dim 4, input
+ * width f <= 16, max_step >= 2), built on the tile SpMM kernel (same gathers, same order of additions per row as
+ * rwk_spmm_csr with row_lanes = 0 / rwk_spmm_csr_compact; col16 not NULL selects the compact columns, val NULL
+ * means every stored value is 1.0).
+ *
+ * rwk_spmm_project_backward: autograd of rwgnn2/model.py:43 and of the first propagation step (model.py:55, i = 1)
+ * together, d_pre = (dx0 + A^T dx1) * x0 * (1 - x0) with A^T as
+ * CSR, partial rows [dW (4, f) | db (4)] (rwk_spmm_project_backward_blocks(n) of them) and d_features (n, f) when
+ * not NULL; red_in (red_p > 32 rows, red_v columns) not NULL: rwk_reduce_rows_to32 of it into red_out32 in the same
+ * launch.
+ *
+ * rwk_hidden_backward_reduce: rwk_hidden_backward and, in the same launch, the column sums of red_in (red_p rows,
+ * red_v <= 64 columns: the projection's partial rows) into red_out. */
+int64_t rwk_spmm_project_backward_blocks(int64_t n);
+int rwk_spmm_project_backward(const float *dx0, const float *dx1, const float *x0, const float *features,
+                              const float *weight, int64_t n, int64_t f, const int32_t *crow_t, const int32_t *col_t,
+                              const int16_t *col16_t, const float *val_t, float *partials, float *d_features,
+                              const float *red_in, int64_t red_p, int64_t red_v, float *red_out32,
+                              rwk_stream_t stream);
+int rwk_hidden_backward_reduce(const float *adj_hidden, const float *ah, const float *z, const float *dz_partials,
+                               int64_t n_partials, int64_t h, int64_t s, int64_t d, int64_t max_step,
+                               float *d_adj_hidden, float *d_features_hidden, const float *red_in, int64_t red_p,
+                               int64_t red_v, float *red_out, rwk_stream_t stream);
 
 /* out[v] = sum_p in[p, v], rows added in a fixed order (p > 32: 32 row blocks of ceil(p/32) rows,
  * each summed by 4 interleaved slices, then the 32 block sums in index order; v <= 64 columns: one

@@ -151,6 +151,7 @@ def test_merged_launches_equal_separate_launches_full_size(name, dev):
     dk = torch.randn(b.n_graphs, hp["max_step"] * hp["hidden_graphs"], generator=g).to(dev)
     runs = []
     try:
+        fn.FUSED_STEP_LAUNCHES = False
         for merged in (True, False):
             fn.MERGED_LAUNCHES = merged
             m.zero_grad(set_to_none=True)
@@ -160,8 +161,38 @@ def test_merged_launches_equal_separate_launches_full_size(name, dev):
                                                                       m.fc.bias)])
     finally:
         fn.MERGED_LAUNCHES = True
+        fn.FUSED_STEP_LAUNCHES = True
     for a, c in zip(*runs):
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("name", ["proteins1024", "proteins1024_deg5", "powerlaw"])
+def test_fused_step_launches_equal_separate_launches_full_size(name, dev):
+    """The first propagation step inside the projection's launches (forward and backward), the hidden-graph backward
+    beside the projection-gradient sum: K and the hidden-graph gradients are the same bits as with the stand-alone
+    SpMM launches (the same additions in the same order); the projection's own gradients are the same per-node terms
+    added in another fixed order."""
+    import gnn_amd.function as fn
+    hp, b, m = build(name, dev)
+    adj, feats, gi, _ = b.to_torch(dev)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    dk = torch.randn(b.n_graphs, hp["max_step"] * hp["hidden_graphs"], generator=g).to(dev)
+    runs = []
+    try:
+        for fused in (True, False):
+            fn.FUSED_STEP_LAUNCHES = fused
+            m.zero_grad(set_to_none=True)
+            k = m.rw_features(adj, feats, gi)
+            k.backward(dk)
+            runs.append([k.detach().clone()] + [p.grad.clone() for p in (m.adj_hidden, m.features_hidden, m.fc.weight,
+                                                                      m.fc.bias)])
+    finally:
+        fn.FUSED_STEP_LAUNCHES = True
+    for a, c in zip(runs[0][:3], runs[1][:3]):
+        assert torch.equal(a, c)
+    for a, c in zip(runs[0][3:], runs[1][3:]):           # sums of 3e5 signed terms in two different fixed orders
+        a64, c64 = a.double().cpu().numpy(), c.double().cpu().numpy()
+        assert np.abs(a64 - c64).max() <= 1e-5 * np.abs(c64).max() + 6e-8 * np.sqrt(b.n_nodes) * 4 * np.abs(dk.cpu().numpy()).max() * np.abs(b.features).max()
 
 
 @pytest.mark.parametrize("name,n_graphs", [("proteins1024", None), ("proteins1024_deg5", None), ("powerlaw", None),

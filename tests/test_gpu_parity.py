@@ -105,11 +105,20 @@ def test_layer_forward_backward(name, dev):
         want["adj_hidden"] = d_adj
     else:
         assert m.adj_hidden.grad is None
+    # fc.bias and fc.weight are sums over all nodes of signed terms d_pre[n] (x features[n]); where they cancel (on
+    # mutag_b0 the bias gradient is 3e-4 against a sum of magnitudes of 0.17) no float32 summation order reaches 1e-5
+    # of the result, so the rounding floor of a float32 sum of N such terms, eps * sqrt(N) * max|term| (with a factor
+    # of 4), is admitted on top - the rule the full-size tests use
+    floor = {"fc.bias": np.abs(d_pre).max(), "fc.weight": np.abs(d_pre).max() * np.abs(c["features"]).max()}
     for key in want:
         # Where cancellation over the nodes keeps even the reference's own float32 gradient further than
         # 1e-5 from the float64 truth, we must be at least as accurate as the reference is.
         ref_own_err = rel_err(c.grads[key], want[key])
-        assert rel_err(got[key].cpu().numpy(), want[key]) < max(TOL, ref_own_err), key
+        err = rel_err(got[key].cpu().numpy(), want[key])
+        bound = max(TOL, ref_own_err)
+        if key in floor:
+            bound += 6e-8 * np.sqrt(c.n_nodes) * 4 * floor[key] / max(np.abs(want[key]).max(), 1e-30)
+        assert err < bound, (key, err, bound)
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -160,6 +169,16 @@ def _float64_port_grads(c):
     return grads
 
 
+def _run_layer(c, dev, adj, feats, gi, dk):
+    m = _model_for(c, dev)
+    fe = feats.clone().requires_grad_(True)
+    k = m.rw_features(adj, fe, gi)
+    k.backward(dk)
+    grads = {n: p.grad for n, p in (("adj_hidden", m.adj_hidden), ("features_hidden", m.features_hidden),
+                                    ("fc.weight", m.fc.weight), ("fc.bias", m.fc.bias)) if p.grad is not None}
+    return dict(grads, k=k.detach(), features=fe.grad)
+
+
 @pytest.mark.parametrize("name", ["mutag_b0", "mutag_b2_norm", "step1", "tiny_graphs_step4"])
 def test_merged_launches_equal_separate_launches(name, dev):
     """The hidden-graph kernels ride in the projection kernels' launches (forward and backward); with the merge
@@ -170,19 +189,47 @@ def test_merged_launches_equal_separate_launches(name, dev):
     dk = torch.from_numpy(c["dk"]).to(dev)
     runs = []
     try:
+        fn.FUSED_STEP_LAUNCHES = False
         for merged in (True, False):
             fn.MERGED_LAUNCHES = merged
-            m = _model_for(c, dev)
-            fe = feats.clone().requires_grad_(True)
-            k = m.rw_features(adj, fe, gi)
-            k.backward(dk)
-            grads = [p.grad for p in (m.adj_hidden, m.features_hidden, m.fc.weight, m.fc.bias) if p.grad is not None]
-            runs.append([k.detach(), fe.grad] + grads)
+            runs.append(_run_layer(c, dev, adj, feats, gi, dk))
     finally:
         fn.MERGED_LAUNCHES = True
-    assert len(runs[0]) == len(runs[1])
-    for a, b in zip(*runs):
-        assert torch.equal(a, b)
+        fn.FUSED_STEP_LAUNCHES = True
+    assert runs[0].keys() == runs[1].keys()
+    for key in runs[0]:
+        assert torch.equal(runs[0][key], runs[1][key]), key
+
+
+@pytest.mark.parametrize("name", ["mutag_b0", "mutag_b1_eval", "mutag_b2_norm", "tiny_graphs_step4",
+                                  "unsorted_indicator", "directed3_dups"])
+def test_fused_step_launches_equal_separate_launches(name, dev):
+    """The first propagation step done inside the projection's launch (forward: X_1 from recomputed neighbour rows;
+    backward: A^T dX_1 gathered by the projection's backward pass) against the stand-alone SpMM launches: the same
+    additions in the same order, so K and the hidden-graph gradients are the same bits; the projection's weight
+    and bias gradients are the same per-node terms added in another (fixed) order."""
+    import gnn_amd.function as fn
+    c = GoldenCase(name)
+    adj, feats, gi, _ = c.torch_inputs(dev)
+    dk = torch.from_numpy(c["dk"]).to(dev)
+    runs = []
+    try:
+        for fused in (True, False):
+            fn.FUSED_STEP_LAUNCHES = fused
+            runs.append(_run_layer(c, dev, adj, feats, gi, dk))
+    finally:
+        fn.FUSED_STEP_LAUNCHES = True
+    assert runs[0].keys() == runs[1].keys()
+    for key in ("k", "adj_hidden", "features_hidden"):
+        if key in runs[0]:
+            assert torch.equal(runs[0][key], runs[1][key]), key
+    assert rel_err(runs[0]["features"].cpu().numpy(), runs[1]["features"].cpu().numpy().astype(np.float64)) < 1e-6
+    # sums of signed per-node terms: equal up to the rounding of a float32 sum of that many terms
+    n_nodes = c.n_nodes
+    for key in ("fc.weight", "fc.bias"):
+        a, b = runs[0][key].cpu().numpy().astype(np.float64), runs[1][key].cpu().numpy().astype(np.float64)
+        scale = np.abs(c["dk"]).max() * max(np.abs(c["features"]).max(), 1.0)
+        assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max() + 6e-8 * np.sqrt(n_nodes) * 4 * scale, key
 
 
 def test_backward_is_bitwise_reproducible(dev):
