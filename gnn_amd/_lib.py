@@ -84,6 +84,10 @@ SIGNATURES = {
     "rwk_fused_reduce_stats": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, c_float, c_int, _P, _P, _P, _P, _P]),
     "rwk_head_apply_loss": (c_int, [_P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, c_float, c_float, _P, _I64, _P,
                                     _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "rwk_head_train_supported": (c_int, [_I64, _I64, _I64, _I64]),
+    "rwk_head_train_forward": (c_int, [_P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, c_float, c_float, _P, _I64, _P,
+                                       _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "rwk_head_train_backward": (c_int, [_P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rwk_reduce_rows_workspace": (_I64, [_I64, _I64]),
     "rwk_reduce_rows": (c_int, [_P, _I64, _I64, _P, _P, _P]),
     "rwk_reduce_rows_level1": (_I64, [_I64]),

@@ -620,7 +620,8 @@ head_bwd_tile_kernel(const float *__restrict__ k, HeadDims dm, const float *__re
             const float *lo = out + (r0 + tid) * nc;
             const float lse = row_lse(lo, nc);
             const float scale = d_loss[0] / (float)dm.g;
-            const long long cls = labels[r0 + tid];
+            long long cls = labels[r0 + tid];
+            cls = cls < 0 ? 0 : (cls >= nc ? nc - 1 : cls);       // as the forward launch does
             float s = 0.f;
             for (int q = 0; q < nc; ++q) s += scale * (expf(lo[q] - lse) - (q == cls ? 1.f : 0.f));
             for (int q = 0; q < nc; ++q) {
@@ -723,6 +724,251 @@ head_bwd_tile_kernel(const float *__restrict__ k, HeadDims dm, const float *__re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// training step: the forward pass and the per-tile part of the backward pass in one launch
+// ---------------------------------------------------------------------------------------------------
+// When the head's output goes straight into the mean cross-entropy and a backward pass will follow (the training
+// step), everything the backward pass does per tile of rows - d(logits) from the log-probabilities and the labels,
+// d(pre-activations), dY, this block's partial parameter sums - needs nothing that the forward pass of the same tile
+// has not just left in LDS.  Doing it there saves a launch, the re-load of the parameters and of the tile, and the
+// store and re-load of the hidden activations.  The gradient of the loss value itself (d_loss, known only when the
+// backward pass runs) is a common factor: everything here is computed for d_loss = 1 and head_bwd_finish_kernel
+// multiplies by it.  Expressions and orders of addition are those of head_apply_kernel and head_bwd_tile_kernel.
+__global__ void __launch_bounds__(kBlock)
+head_train_kernel(const float *__restrict__ k, HeadDims dm, const float *__restrict__ bn_w,
+                  const float *__restrict__ bn_b, float *running_mean, float *running_var,
+                  long long *num_batches_tracked, float momentum, float eps, const float *__restrict__ partials,
+                  int n_partials, const float *__restrict__ w1, const float *__restrict__ b1,
+                  const float *__restrict__ w2, const float *__restrict__ b2, float drop_p,
+                  const unsigned long long *__restrict__ rng, float *__restrict__ mean_out,
+                  float *__restrict__ invstd_out, float *__restrict__ out, const long long *__restrict__ labels,
+                  float *__restrict__ loss_partials, float *__restrict__ dy, float *__restrict__ grad_partials) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int c = dm.c, p = dm.p, nc = dm.nc;
+    const int cs = c + 1, ps = p + 1;
+    const int nv = head_nv(c, p, nc);
+    float nll = 0.f;
+    float *s_w1 = lds;                       // [p][cs]
+    float *s_w2 = s_w1 + p * cs;             // [nc][ps]
+    float *s_b1 = s_w2 + nc * ps;            // [p]
+    float *s_b2 = s_b1 + p;                  // [nc]
+    float *s_scale = s_b2 + nc;              // [c]  gamma * invstd
+    float *s_shift = s_scale + c;            // [c]  beta - mean * gamma * invstd
+    float *s_mu = s_shift + c;               // [c]
+    float *s_is = s_mu + c;                  // [c]
+    float *s_ga = s_is + c;                  // [c]
+    float *s_be = s_ga + c;                  // [c]
+    float *s_y = s_be + c;                   // [kRows][cs]  batch-norm output, later dY
+    float *s_xh = s_y + kRows * cs;          // [kRows][cs]  normalised input
+    float *s_h = s_xh + kRows * cs;          // [kRows][ps]  hidden activations after dropout
+    float *s_dp = s_h + kRows * ps;          // [kRows][ps]  gradient of the first layer's pre-activation
+    float *s_o = s_dp + kRows * ps;          // [kRows][nc]  logits
+    float *s_dl = s_o + kRows * nc;          // [kRows][nc]  gradient of the logits
+    float *s_g = s_dl + kRows * nc;          // [nv]
+    const int tid = threadIdx.x;
+    const FastDiv by_c(c), by_p(p), by_nc(nc);
+
+    ParamChunk<4> r_w1;
+    ParamChunk<1> r_w2, r_b1, r_b2;
+    ParamChunk<2> r_k;
+    r_w1.load(w1, p * c, tid);
+    r_w2.load(w2, nc * p, tid);
+    r_b1.load(b1, p, tid);
+    r_b2.load(b2, nc, tid);
+    {
+        const long long r0 = (long long)blockIdx.x * kRows;
+        const int nr = (int)(dm.g - r0 < kRows ? dm.g - r0 : kRows);
+        r_k.load(k + r0 * c, nr * c, tid);
+    }
+    for (int i = tid; i < nv; i += kBlock) s_g[i] = 0.f;
+    const int lane8 = tid & 7;
+    int c0 = 0;
+    do {                                                      // uniform trip count: the shuffles need all lanes
+        const int col_raw = c0 + (tid >> 3);
+        const int col = col_raw < c ? col_raw : c - 1;
+        StatsChunk first;
+        first.load(partials, n_partials, c, col, lane8);
+        const float rm = running_mean[col], rv = running_var[col], ga = bn_w[col], be = bn_b[col];
+        if (c0 == 0) {
+            r_w1.store_rows(w1, p * c, by_c, cs, s_w1, tid);
+            r_w2.store_rows(w2, nc * p, by_p, ps, s_w2, tid);
+            r_b1.store_flat(b1, p, s_b1, tid);
+            r_b2.store_flat(b2, nc, s_b2, tid);
+        }
+        float var;
+        const float mean = merge_stats8(partials, n_partials, c, col, lane8, first, &var);
+        if (lane8 == 0 && col_raw < c) {
+            if (blockIdx.x == 0) {
+                const float unbiased = dm.g > 1 ? var * ((float)dm.g / (float)(dm.g - 1)) : var;
+                running_mean[col] = (1.f - momentum) * rm + momentum * mean;
+                running_var[col] = (1.f - momentum) * rv + momentum * unbiased;
+                if (col == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
+            }
+            const float invstd = 1.f / sqrtf(var + eps);
+            if (blockIdx.x == 0) {
+                mean_out[col] = mean;
+                invstd_out[col] = invstd;
+            }
+            const float sc = ga * invstd;
+            s_scale[col] = sc;
+            s_shift[col] = be - mean * sc;
+            s_mu[col] = mean;
+            s_is[col] = invstd;
+            s_ga[col] = ga;
+            s_be[col] = be;
+        }
+        c0 += kBlock / 8;
+    } while (c0 < c);
+    __syncthreads();
+
+    const bool drop = drop_p > 0.f;
+    uint32_t seed_lo = 0, key_hi = 0, off_lo = 0, keep_thr = 0xFFFFFFFFu;
+    float keep_scale = 1.f;
+    if (drop) {
+        const unsigned long long seed = rng[0], off = rng[1];
+        seed_lo = (uint32_t)seed;
+        key_hi = (uint32_t)(seed >> 32) ^ (uint32_t)(off >> 32);
+        off_lo = (uint32_t)off;
+        const double q = 1.0 - (double)drop_p;
+        const double thr = q * 4294967296.0;
+        keep_thr = thr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)thr;
+        keep_scale = 1.f / (1.f - drop_p);
+    }
+    const int o_b2 = nc * p, o_w1 = o_b2 + nc, o_b1 = o_w1 + p * c, o_ga = o_b1 + p, o_be = o_ga + c;
+    const float inv_g = 1.f / (float)dm.g;          // d(mean loss) / d(row loss), for d_loss = 1
+
+    const long long n_tiles = (dm.g + kRows - 1) / kRows;
+    for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const long long r0 = t * kRows;
+        const int nr = (int)(dm.g - r0 < kRows ? dm.g - r0 : kRows);
+        const bool first_tile = t == blockIdx.x;
+        // ---- forward (head_apply_kernel) ----
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * kBlock;
+            const int r = by_c.div(i), col = i - r * c;
+            if (first_tile && i < nr * c) {
+                s_y[r * cs + col] = fmaf(r_k.v[u], s_scale[col], s_shift[col]);
+                s_xh[r * cs + col] = (r_k.v[u] - s_mu[col]) * s_is[col];
+            }
+        }
+        for (int i = tid + (first_tile ? 2 * kBlock : 0); i < nr * c; i += kBlock) {
+            const int r = by_c.div(i), col = i - r * c;
+            const float kv = k[(r0 + r) * c + col];
+            s_y[r * cs + col] = fmaf(kv, s_scale[col], s_shift[col]);
+            s_xh[r * cs + col] = (kv - s_mu[col]) * s_is[col];
+        }
+        __syncthreads();
+        for (int i = tid; i < nr * p; i += kBlock) {
+            const int r = by_p.div(i), j = i - r * p;
+            float acc = s_b1[j];
+            const float *yr = s_y + r * cs, *wr = s_w1 + j * cs;
+#pragma unroll 8
+            for (int col = 0; col < c; ++col) acc = fmaf(yr[col], wr[col], acc);
+            acc = acc > 0.f ? acc : 0.f;
+            if (drop) {
+                const RwkPhilox4 rr = rwk_philox4x32_10((uint32_t)(r0 + r), (uint32_t)(j >> 2), kHeadCall, off_lo,
+                                                        seed_lo, key_hi);
+                const uint32_t wv[4] = {rr.x, rr.y, rr.z, rr.w};
+                acc = wv[j & 3] < keep_thr ? acc * keep_scale : 0.f;
+            }
+            s_h[r * ps + j] = acc;
+        }
+        __syncthreads();
+        for (int i = tid; i < nr * nc; i += kBlock) {
+            const int r = by_nc.div(i), q = i - r * nc;
+            float acc = s_b2[q];
+            const float *hr = s_h + r * ps, *wr = s_w2 + q * ps;
+#pragma unroll 8
+            for (int j = 0; j < p; ++j) acc = fmaf(hr[j], wr[j], acc);
+            s_o[r * nc + q] = acc;
+        }
+        __syncthreads();
+        if (tid < nr) {
+            float *o = s_o + tid * nc;
+            float mx = o[0];
+            for (int q = 1; q < nc; ++q) mx = fmaxf(mx, o[q]);
+            float se = 0.f;
+            for (int q = 0; q < nc; ++q) se += expf(o[q] - mx);
+            const float lse = mx + logf(se);
+            for (int q = 0; q < nc; ++q) {
+                o[q] -= lse;                                 // the stored log-probabilities
+                out[(r0 + tid) * nc + q] = o[q];
+            }
+            // cross-entropy of the stored log-probabilities and its gradient (head_bwd_tile_kernel, d_loss = 1)
+            const float lse2 = row_lse(o, nc);
+            long long cls = labels[r0 + tid];
+            cls = cls < 0 ? 0 : (cls >= nc ? nc - 1 : cls);  // the host side has checked the range (see head.py)
+            nll += lse2 - o[cls];
+            float sgo = 0.f;
+            for (int q = 0; q < nc; ++q) sgo += inv_g * (expf(o[q] - lse2) - (q == cls ? 1.f : 0.f));
+            for (int q = 0; q < nc; ++q) {
+                const float go = inv_g * (expf(o[q] - lse2) - (q == cls ? 1.f : 0.f));
+                s_dl[tid * nc + q] = go - expf(o[q]) * sgo;
+            }
+        }
+        __syncthreads();
+        // ---- backward, per-tile part (head_bwd_tile_kernel) ----
+        for (int i = tid; i < nr * p; i += kBlock) {
+            const int r = by_p.div(i), j = i - r * p;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int q = 0; q < nc; ++q) acc = fmaf(s_dl[r * nc + q], s_w2[q * ps + j], acc);
+            s_dp[r * ps + j] = s_h[r * ps + j] > 0.f ? acc * keep_scale : 0.f;
+        }
+        __syncthreads();
+        for (int i = tid; i < nr * c; i += kBlock) {
+            const int r = by_c.div(i), col = i - r * c;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < p; ++j) acc = fmaf(s_dp[r * ps + j], s_w1[j * cs + col], acc);
+            s_y[r * cs + col] = acc;                         // dY: the batch-norm output is no longer needed
+            dy[(r0 + r) * c + col] = acc;
+        }
+        __syncthreads();
+        for (int e = tid; e < nv; e += kBlock) {
+            float acc = 0.f;
+            if (e < o_b2) {
+                const int q = by_p.div(e), j = e - q * p;
+#pragma unroll 8
+                for (int r = 0; r < nr; ++r) acc = fmaf(s_dl[r * nc + q], s_h[r * ps + j], acc);
+            } else if (e < o_w1) {
+                const int q = e - o_b2;
+#pragma unroll 8
+                for (int r = 0; r < nr; ++r) acc += s_dl[r * nc + q];
+            } else if (e < o_b1) {
+                const int j = by_c.div(e - o_w1), col = (e - o_w1) - j * c;
+                const float ga = s_ga[col], be = s_be[col];
+#pragma unroll 8
+                for (int r = 0; r < nr; ++r) acc = fmaf(s_dp[r * ps + j], fmaf(s_xh[r * cs + col], ga, be), acc);
+            } else if (e < o_ga) {
+                const int j = e - o_b1;
+#pragma unroll 8
+                for (int r = 0; r < nr; ++r) acc += s_dp[r * ps + j];
+            } else if (e < o_be) {
+                const int col = e - o_ga;
+#pragma unroll 8
+                for (int r = 0; r < nr; ++r) acc = fmaf(s_y[r * cs + col], s_xh[r * cs + col], acc);
+            } else {
+                const int col = e - o_be;
+#pragma unroll 8
+                for (int r = 0; r < nr; ++r) acc += s_y[r * cs + col];
+            }
+            s_g[e] += acc;
+        }
+        __syncthreads();
+    }
+    float *dst = grad_partials + (size_t)blockIdx.x * nv;
+    for (int e = tid; e < nv; e += kBlock) dst[e] = s_g[e];
+    if (tid < kRows) s_o[tid] = nll;                         // this block's share of the loss sum, row lanes in order
+    __syncthreads();
+    if (tid == 0) {
+        float acc = 0.f;
+        for (int r = 0; r < kRows; ++r) acc += s_o[r];
+        loss_partials[blockIdx.x] = acc;
+    }
+}
+
 // partials[b][e] added over b = lane8, lane8 + 8, ... in that order, eight loads in flight at a time
 __device__ inline float sum_partials8(const float *__restrict__ partials, int n_partials, int nv, int e, int lane8) {
     float acc = 0.f;
@@ -747,12 +993,29 @@ __global__ void __launch_bounds__(kBlock)
 head_bwd_finish_kernel(const float *__restrict__ k, HeadDims dm, const float *__restrict__ bn_w,
                        const float *__restrict__ mean, const float *__restrict__ invstd,
                        const float *__restrict__ dy, const float *__restrict__ partials, int n_partials, int training,
-                       float *__restrict__ grads, float *__restrict__ d_k) {
+                       float *__restrict__ grads, float *__restrict__ d_k, const float *__restrict__ d_loss,
+                       const float *__restrict__ loss_partials, float *__restrict__ loss_out) {
     __shared__ float s_dga[kMaxC], s_dbe[kMaxC];
     const int c = dm.c, p = dm.p, nc = dm.nc;
     const int nv = head_nv(c, p, nc);
     const int tid = threadIdx.x;
     const int o_ga = nc * p + nc + p * c + p;
+    // d_loss not null: dy and the partials were computed for d(loss) = 1 (head_train_kernel) and take the factor here
+    const float dl = d_loss != nullptr ? d_loss[0] : 1.f;
+    if (loss_out != nullptr && blockIdx.x == gridDim.x - 1 && tid < 64) {
+        // mean loss from the forward launch's per-block sums: lane l adds blocks l, l + 64, ... in order (at most
+        // kMaxBlocks = 256: four loads in flight), then a butterfly whose operand pairs are fixed
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int b = tid + 64 * u;
+            v[u] = loss_partials[b < n_partials ? b : n_partials - 1];
+            if (b >= n_partials) v[u] = 0.f;
+        }
+        float acc = ((v[0] + v[1]) + v[2]) + v[3];
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (tid == 0) loss_out[0] = acc / (float)dm.g;
+    }
     // this block's slice of the parameter gradients: eight lanes share the block partials of one element
     // (independent loads in flight) and are then added in a fixed butterfly order
     const int lane8 = tid & 7, grp = tid >> 3;
@@ -765,7 +1028,7 @@ head_bwd_finish_kernel(const float *__restrict__ k, HeadDims dm, const float *__
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
         acc += __shfl_xor(acc, 4, 64);
-        if (lane8 == 0 && e < e_hi) grads[e] = acc;
+        if (lane8 == 0 && e < e_hi) grads[e] = acc * dl;
     }
     if (d_k == nullptr) return;
     for (int c0 = 0; c0 < 2 * c; c0 += kBlock / 8) {
@@ -776,7 +1039,7 @@ head_bwd_finish_kernel(const float *__restrict__ k, HeadDims dm, const float *__
         acc += __shfl_xor(acc, 2, 64);
         acc += __shfl_xor(acc, 4, 64);
         if (lane8 == 0 && q < 2 * c) {
-            if (q < c) s_dga[q] = acc; else s_dbe[q - c] = acc;
+            if (q < c) s_dga[q] = acc * dl; else s_dbe[q - c] = acc * dl;
         }
     }
     __syncthreads();
@@ -790,7 +1053,7 @@ head_bwd_finish_kernel(const float *__restrict__ k, HeadDims dm, const float *__
             const int col = by_c.mod(i);
             const long long at = r0 * c + i;
             const float sc = bn_w[col] * invstd[col];
-            float v = dy[at];
+            float v = dy[at] * dl;
             if (training) {
                 const float xh = (k[at] - mean[col]) * invstd[col];
                 v = v - s_dbe[col] * inv_g - xh * s_dga[col] * inv_g;
@@ -815,7 +1078,7 @@ cross_entropy_forward_kernel(const float *__restrict__ x, const long long *__res
     for (long long r = threadIdx.x; r < g; r += kCeBlock) {
         const float *row = x + r * nc;
         long long cls = y[r];
-        cls = cls < 0 ? 0 : (cls >= nc ? nc - 1 : cls);           // labels are validated on the host side
+        cls = cls < 0 ? 0 : (cls >= nc ? nc - 1 : cls);           // the host side checks the range once per label tensor
         acc += row_lse(row, nc) - row[cls];
     }
     red[threadIdx.x] = acc;
@@ -835,7 +1098,8 @@ cross_entropy_backward_kernel(const float *__restrict__ x, const long long *__re
     const float *row = x + r * nc;
     const float lse = row_lse(row, nc);
     const float scale = d_loss[0] / (float)g;
-    const long long cls = y[r];
+    long long cls = y[r];
+    cls = cls < 0 ? 0 : (cls >= nc ? nc - 1 : cls);               // as the forward kernel does
     for (int q = 0; q < nc; ++q) d_x[r * nc + q] = scale * (expf(row[q] - lse) - (q == cls ? 1.f : 0.f));
 }
 
@@ -846,6 +1110,12 @@ size_t fwd_lds(int c, int p, int nc) {
 size_t bwd_lds(int c, int p, int nc) {
     return sizeof(float) * ((size_t)p * (c + 1) + (size_t)nc * (p + 1) + 2 * (size_t)kRows * (c + 1) +
                             2 * (size_t)kRows * (p + 1) + (size_t)kRows * nc + head_nv(c, p, nc) + 2 * (size_t)c);
+}
+
+size_t train_lds(int c, int p, int nc) {
+    return sizeof(float) * ((size_t)p * (c + 1) + (size_t)nc * (p + 1) + p + nc + 6 * (size_t)c +
+                            2 * (size_t)kRows * (c + 1) + 2 * (size_t)kRows * (p + 1) + 2 * (size_t)kRows * nc +
+                            head_nv(c, p, nc));
 }
 
 bool dims_ok(int64_t g, int64_t c, int64_t p, int64_t nc) {
@@ -1073,7 +1343,85 @@ int rwk_head_backward_loss(const float *k, int64_t g, int64_t c, int64_t p, int6
                        loss_partials, blocks, loss);
     RWK_LAUNCH_CHECK();
     hipLaunchKernelGGL(head_bwd_finish_kernel, dim3(blocks), dim3(kBlock), 0, stream, k, dm, bn_w, mean, invstd, dy,
-                       partials, blocks, training, grads, d_k);
+                       partials, blocks, training, grads, d_k, (const float *)nullptr, (const float *)nullptr,
+                       (float *)nullptr);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
+int rwk_head_train_supported(int64_t g, int64_t c, int64_t p, int64_t nc) {
+    return rwk_head_supported(g, c, p, nc) && g >= 2 && train_lds((int)c, (int)p, (int)nc) <= 150 * 1024 ? 1 : 0;
+}
+
+int rwk_head_train_forward(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
+                           const float *bn_b, float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                           float momentum, float eps, float *stats, int64_t n_stats_ready, const float *w1,
+                           const float *b1, const float *w2, const float *b2, float drop_p, uint64_t *rng_state,
+                           uint64_t *rng_used, float *mean_out, float *invstd_out, float *out, const int64_t *labels,
+                           float *loss_partials, float *dy, float *partials, rwk_stream_t stream_) {
+    RWK_REQUIRE_PTR(k);
+    RWK_REQUIRE_PTR(bn_w);
+    RWK_REQUIRE_PTR(bn_b);
+    RWK_REQUIRE_PTR(running_mean);
+    RWK_REQUIRE_PTR(running_var);
+    RWK_REQUIRE_PTR(stats);
+    RWK_REQUIRE_PTR(w1);
+    RWK_REQUIRE_PTR(b1);
+    RWK_REQUIRE_PTR(w2);
+    RWK_REQUIRE_PTR(b2);
+    RWK_REQUIRE_PTR(mean_out);
+    RWK_REQUIRE_PTR(invstd_out);
+    RWK_REQUIRE_PTR(out);
+    RWK_REQUIRE_PTR(labels);
+    RWK_REQUIRE_PTR(loss_partials);
+    RWK_REQUIRE_PTR(dy);
+    RWK_REQUIRE_PTR(partials);
+    if (!rwk_head_train_supported(g, c, p, nc)) return RWK_E_UNSUPPORTED;
+    if (drop_p < 0.f || drop_p >= 1.f) return RWK_E_SIZE;
+    if (n_stats_ready < 0 || n_stats_ready > kMaxFusedStatsBlocks) return RWK_E_SIZE;
+    const bool drop = drop_p > 0.f;
+    if (drop) {
+        RWK_REQUIRE_PTR(rng_used);
+        if (n_stats_ready == 0) RWK_REQUIRE_PTR(rng_state);
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    const HeadDims dm{(long long)g, (int)c, (int)p, (int)nc};
+    if (n_stats_ready == 0) {
+        hipLaunchKernelGGL(head_stats_kernel, dim3(head_stats_blocks(g)), dim3(kBlock), 0, stream, k, (long long)g,
+                           (int)c, stats, drop ? (unsigned long long *)rng_state : nullptr,
+                           drop ? (unsigned long long *)rng_used : nullptr);
+        RWK_LAUNCH_CHECK();
+    }
+    const int n_stats = n_stats_ready > 0 ? (int)n_stats_ready : head_stats_blocks(g);
+    const size_t lds = train_lds((int)c, (int)p, (int)nc);
+    const int rc = allow_lds(head_train_kernel, lds);
+    if (rc != RWK_OK) return rc;
+    hipLaunchKernelGGL(head_train_kernel, dim3(head_blocks(g)), dim3(kBlock), lds, stream, k, dm, bn_w, bn_b,
+                       running_mean, running_var, (long long *)num_batches_tracked, momentum, eps,
+                       (const float *)stats, n_stats, w1, b1, w2, b2, drop_p, (const unsigned long long *)rng_used,
+                       mean_out, invstd_out, out, (const long long *)labels, loss_partials, dy, partials);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
+int rwk_head_train_backward(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
+                            const float *mean, const float *invstd, const float *dy, const float *partials,
+                            const float *d_loss, const float *loss_partials, float *loss, float *grads, float *d_k,
+                            rwk_stream_t stream_) {
+    RWK_REQUIRE_PTR(k);
+    RWK_REQUIRE_PTR(bn_w);
+    RWK_REQUIRE_PTR(mean);
+    RWK_REQUIRE_PTR(invstd);
+    RWK_REQUIRE_PTR(dy);
+    RWK_REQUIRE_PTR(partials);
+    RWK_REQUIRE_PTR(d_loss);
+    RWK_REQUIRE_PTR(grads);
+    if ((loss == nullptr) != (loss_partials == nullptr)) return RWK_E_NULL;
+    if (!rwk_head_train_supported(g, c, p, nc)) return RWK_E_UNSUPPORTED;
+    const int blocks = head_blocks(g);
+    const HeadDims dm{(long long)g, (int)c, (int)p, (int)nc};
+    hipLaunchKernelGGL(head_bwd_finish_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream_, k, dm, bn_w, mean,
+                       invstd, dy, partials, blocks, 1, grads, d_k, d_loss, loss_partials, loss);
     RWK_LAUNCH_CHECK();
     return RWK_OK;
 }

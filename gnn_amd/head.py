@@ -18,6 +18,27 @@ def head_supported(n_graphs: int, n_features: int, penultimate_dim: int, n_class
     return bool(_lib.load().rwk_head_supported(n_graphs, n_features, penultimate_dim, n_classes))
 
 
+_CHECKED_LABELS = {}
+
+
+def check_labels(labels, n_classes: int):
+    """Class indices must lie in [0, n_classes), as ``F.cross_entropy`` requires (it raises otherwise; the kernels
+    would clamp silently).  One device-to-host read per label tensor: the result is remembered by tensor identity
+    and version, batches being reused every epoch (``rwgnn2/main.py:70-72``)."""
+    key = (labels.data_ptr(), labels._version, labels.numel(), int(n_classes))
+    if _CHECKED_LABELS.get(key):
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return                                            # no host read under graph capture; warm-up steps came first
+    if labels.numel():
+        lo, hi = int(labels.min().item()), int(labels.max().item())
+        if lo < 0 or hi >= n_classes:
+            raise IndexError(f"Target {lo if lo < 0 else hi} is out of bounds for {n_classes} classes")
+    if len(_CHECKED_LABELS) > 4096:
+        _CHECKED_LABELS.clear()
+    _CHECKED_LABELS[key] = True
+
+
 def _launch_forward(lib, kc, g, c, p, nc, bn_wc, bn_bc, running_mean, running_var, num_batches_tracked, momentum, eps,
                     training, w1c, b1c, w2c, b2c, drop, rng_state, mean, invstd, h1d, out, labels, loss_partials,
                     handoff, stream):
@@ -43,6 +64,19 @@ def _launch_forward(lib, kc, g, c, p, nc, bn_wc, bn_bc, running_mean, running_va
         _lib.ptr(stats), w1c.data_ptr(), b1c.data_ptr(), w2c.data_ptr(), b2c.data_ptr(), drop,
         _lib.ptr(rng_state) if drop else None, _lib.ptr(rng_used), _lib.ptr(mean), _lib.ptr(invstd),
         _lib.ptr(h1d), out.data_ptr(), _lib.ptr(labels), _lib.ptr(loss_partials), stream), "rwk_head_forward_loss")
+
+
+def _split_grads(grads, c, p, nc):
+    """(d_bn_w, d_bn_b, d_w1, d_b1, d_w2, d_b2) views of the kernels' gradient vector
+    [dW2 (nc*p) | db2 (nc) | dW1 (p*c) | db1 (p) | dgamma (c) | dbeta (c)]."""
+    o = 0
+    d_w2 = grads[o:o + nc * p].view(nc, p); o += nc * p
+    d_b2 = grads[o:o + nc]; o += nc
+    d_w1 = grads[o:o + p * c].view(p, c); o += p * c
+    d_b1 = grads[o:o + p]; o += p
+    d_bn_w = grads[o:o + c]; o += c
+    d_bn_b = grads[o:o + c]
+    return d_bn_w, d_bn_b, d_w1, d_b1, d_w2, d_b2
 
 
 class _FusedHead(torch.autograd.Function):
@@ -133,9 +167,12 @@ class _FusedHeadLoss(torch.autograd.Function):
         if labels.dtype != torch.int64 or labels.shape != (g,) or labels.device != dev:
             raise ValueError("labels must be an int64 tensor of one class index per graph on the device of k")
         drop = float(drop_p) if (training and drop_p and rng_state is not None) else 0.0
+        check_labels(labels, nc)
         # grad_mode: the caller's torch.is_grad_enabled() (inside forward() it is always off, and
         # needs_input_grad reports requires_grad of the inputs whatever the mode)
         needs_grad = bool(grad_mode) and any(ctx.needs_input_grad[:1] + ctx.needs_input_grad[2:8])
+        # training step: the tile part of the backward pass runs in the forward launch (rwk_head_train_forward)
+        train_fused = needs_grad and training and bool(lib.rwk_head_train_supported(g, c, p, nc))
         with _lib.device_guard(dev):
             stream = _lib.current_stream(dev)
             kc = k.detach().contiguous()
@@ -146,16 +183,41 @@ class _FusedHeadLoss(torch.autograd.Function):
             keep = training or needs_grad
             mean = torch.empty(c, dtype=torch.float32, device=dev) if keep else None
             invstd = torch.empty(c, dtype=torch.float32, device=dev) if keep else None
-            h1d = torch.empty((g, p), dtype=torch.float32, device=dev) if needs_grad else None
             loss_partials = torch.empty(lib.rwk_head_n_blocks(g), dtype=torch.float32, device=dev) if needs_grad \
                 else None
+            if train_fused:
+                blocks = lib.rwk_head_n_blocks(g)
+                dy = torch.empty((g, c), dtype=torch.float32, device=dev)
+                partials = torch.empty((blocks, lib.rwk_head_grad_size(c, p, nc)), dtype=torch.float32, device=dev)
+                ready = handoff is not None and handoff.get("stats") is not None
+                if ready:
+                    stats, n_stats, rng_used = handoff["stats"], int(handoff["n_stats"]), handoff.get("rng_used")
+                    if drop and rng_used is None:
+                        raise RuntimeError("the statistics handoff does not carry the head's generator state")
+                else:
+                    stats = torch.empty(lib.rwk_head_stats_size(g, c), dtype=torch.float32, device=dev)
+                    n_stats = 0
+                    rng_used = torch.empty(2, dtype=torch.int64, device=dev) if drop else None
+                _lib.check(lib.rwk_head_train_forward(
+                    kc.data_ptr(), g, c, p, nc, bn_wc.data_ptr(), bn_bc.data_ptr(), running_mean.data_ptr(),
+                    running_var.data_ptr(), _lib.ptr(num_batches_tracked), float(momentum), float(eps),
+                    stats.data_ptr(), n_stats, w1c.data_ptr(), b1c.data_ptr(), w2c.data_ptr(), b2c.data_ptr(), drop,
+                    _lib.ptr(rng_state) if (drop and not ready) else None, _lib.ptr(rng_used) if drop else None,
+                    mean.data_ptr(), invstd.data_ptr(), out.data_ptr(), yc.data_ptr(), loss_partials.data_ptr(),
+                    dy.data_ptr(), partials.data_ptr(), stream), "rwk_head_train_forward")
+                ctx.cfg = (training, drop, True)
+                ctx.save_for_backward(kc, bn_wc, mean, invstd, dy, partials, loss_partials, loss)
+                ctx.sizes = (p, nc)
+                ctx.mark_non_differentiable(out)
+                return out, loss
+            h1d = torch.empty((g, p), dtype=torch.float32, device=dev) if needs_grad else None
             _launch_forward(lib, kc, g, c, p, nc, bn_wc, bn_bc, running_mean, running_var, num_batches_tracked,
                             momentum, eps, training, w1c, b1c, w2c, b2c, drop, rng_state, mean, invstd, h1d, out,
                             yc if needs_grad else None, loss_partials, handoff, stream)
             if not needs_grad:
                 _lib.check(lib.rwk_cross_entropy_forward(out.data_ptr(), yc.data_ptr(), g, nc, loss.data_ptr(),
                                                          stream), "rwk_cross_entropy_forward")
-        ctx.cfg = (training, drop)
+        ctx.cfg = (training, drop, False)
         ctx.save_for_backward(kc, yc, bn_wc, bn_bc, w1c, w2c, mean, invstd, h1d, out, loss_partials, loss)
         ctx.mark_non_differentiable(out)
         return out, loss
@@ -164,8 +226,23 @@ class _FusedHeadLoss(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, _d_out, d_loss):
         lib = _lib.load()
+        training, drop, train_fused = ctx.cfg
+        if train_fused:
+            kc, bn_wc, mean, invstd, dy, partials, loss_partials, loss = ctx.saved_tensors
+            g, c = kc.shape
+            p, nc = ctx.sizes
+            dev = kc.device
+            with _lib.device_guard(dev):
+                stream = _lib.current_stream(dev)
+                d_loss = d_loss.contiguous().float()
+                grads = torch.empty(lib.rwk_head_grad_size(c, p, nc), dtype=torch.float32, device=dev)
+                d_k = torch.empty((g, c), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+                _lib.check(lib.rwk_head_train_backward(
+                    kc.data_ptr(), g, c, p, nc, bn_wc.data_ptr(), mean.data_ptr(), invstd.data_ptr(), dy.data_ptr(),
+                    partials.data_ptr(), d_loss.data_ptr(), loss_partials.data_ptr(), loss.data_ptr(),
+                    grads.data_ptr(), _lib.ptr(d_k), stream), "rwk_head_train_backward")
+            return (d_k, None) + _split_grads(grads, c, p, nc) + (None,) * 10
         kc, yc, bn_wc, bn_bc, w1c, w2c, mean, invstd, h1d, out, loss_partials, loss = ctx.saved_tensors
-        training, drop = ctx.cfg
         g, c = kc.shape
         p, nc = w1c.shape[0], w2c.shape[0]
         dev = kc.device

@@ -306,6 +306,26 @@ int rwk_head_apply_loss(const float *k, int64_t g, int64_t c, int64_t p, int64_t
                         float *mean_out, float *invstd_out, float *h1d_out, float *out, const int64_t *labels,
                         float *loss_partials, rwk_stream_t stream);
 
+/* The head of the training step (model.py:68-72 followed by F.cross_entropy, rwgnn2/main.py:84-85) with the per-tile
+ * part of its backward pass done in the forward launch, where the tile's activations are still in LDS: out, per-block
+ * loss sums, dy (g, c) and per-block parameter-gradient rows (rwk_head_n_blocks(g) x rwk_head_grad_size) for
+ * d(loss) = 1.  n_stats_ready > 0: stats holds that many block partials (rwk_fused_reduce_stats) and rng_used the
+ * drawn generator state; 0: the statistics launch runs first, as in rwk_head_forward.  rwk_head_train_backward is
+ * the one launch of the backward pass: multiplies by d_loss[0], adds the partial rows in block order (grads, layout
+ * of rwk_head_backward), forms d_k and finishes the mean loss.  Training mode only; rwk_head_train_supported says
+ * whether the sizes fit (both passes share one LDS allocation). */
+int rwk_head_train_supported(int64_t g, int64_t c, int64_t p, int64_t nc);
+int rwk_head_train_forward(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
+                           const float *bn_b, float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                           float momentum, float eps, float *stats, int64_t n_stats_ready, const float *w1,
+                           const float *b1, const float *w2, const float *b2, float drop_p, uint64_t *rng_state,
+                           uint64_t *rng_used, float *mean_out, float *invstd_out, float *out, const int64_t *labels,
+                           float *loss_partials, float *dy, float *partials, rwk_stream_t stream);
+int rwk_head_train_backward(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
+                            const float *mean, const float *invstd, const float *dy, const float *partials,
+                            const float *d_loss, const float *loss_partials, float *loss, float *grads, float *d_k,
+                            rwk_stream_t stream);
+
 /* Mean cross-entropy of (g, nc) scores against int64 labels in [0, nc): F.cross_entropy with its
  * default arguments, as rwgnn2/main.py:85,92 applies it to the model's output.  loss: device
  * float[1].  Backward: d_scores = d_loss[0] / g * (softmax(scores) - onehot(labels)).
