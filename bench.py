@@ -64,6 +64,12 @@ def parse_args():
                     help="with --kernels-only: also launch a 1 GiB elementwise read+write, the known byte count "
                          "the FETCH_SIZE / WRITE_SIZE counter passes are calibrated on")
     ap.add_argument("--only", default="", help="with --kernels-only: comma-separated kernel classes to launch")
+    ap.add_argument("--capture-allreduce", action="store_true",
+                    help="--gpus N > 1: try to capture the gradient all-reduce inside the step graph (falls back to "
+                         "two graphs around an eager collective if the capture is refused); also RWK_CAPTURE_ALLREDUCE=1")
+    ap.add_argument("--dp-shape", type=int, default=0,
+                    help="one GPU only: time the step in the shape a rank of an N-rank run executes (two graphs and "
+                         "the collective's slot between them, no process group) to see what the shape itself costs")
     return ap.parse_args()
 
 
@@ -325,7 +331,10 @@ def main():
     model.train()
     model.seed_dropout(1234 + rank)
     broadcast_parameters(model)
-    tr = Trainer(model, batch_t, world, args.optimizer, sync_before_all_reduce=backend != "nccl")
+    shape_world = args.dp_shape if (world == 1 and args.dp_shape > 1) else world
+    capture_collective = args.capture_allreduce or os.environ.get("RWK_CAPTURE_ALLREDUCE", "0") == "1"
+    tr = Trainer(model, batch_t, shape_world, args.optimizer, sync_before_all_reduce=backend != "nccl",
+                 capture_collective=capture_collective and world > 1)
     launch = args.mode
     if args.mode == "graph":
         try:
@@ -361,6 +370,8 @@ def main():
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         n_graphs_total = int(c.item())
     loss = float(tr.loss.item())
+    # where a data-parallel step spends its time (every rank runs it: the collective needs them all)
+    phases = tr.phase_times() if (launch == "graph" and shape_world > 1) else None
 
     if rank == 0:
         result = {
@@ -386,6 +397,12 @@ def main():
             },
             "final_loss": round(loss, 5),
         }
+        if shape_world != world:
+            result["config"]["launch"] += f"; step in the shape of a {shape_world}-rank run (no process group)"
+        if phases is not None:
+            result["phases"] = phases
+        if tr.capture_note:
+            result["config"]["launch"] += "; " + tr.capture_note
         if not args.no_kernel_timing:
             kern = time_kernels(batch_t, hp)
             result["kernel_shape"] = kern.pop("_shape")

@@ -32,7 +32,7 @@ class Trainer:
 
     def __init__(self, model, batch_t, world: int = 1, optimizer: str = "flat", lr: float = 1e-2,
                  fused_loss: bool = True, capture_error_mode: str = None, sync_before_all_reduce: bool = False,
-                 forward_fn=None):
+                 forward_fn=None, capture_collective: bool = False):
         self.model = model
         self.adj, self.feats, self.gi, self.y = batch_t
         # forward_fn(): the model's scores for the resident batch, for models with another call signature than
@@ -58,6 +58,11 @@ class Trainer:
         # Under data parallelism the collective library's watchdog thread polls events while the step is being
         # captured; "thread_local" keeps its calls from invalidating the capture.
         self.capture_error_mode = capture_error_mode or ("thread_local" if world > 1 else "global")
+        # world > 1: try to capture the gradient all-reduce inside the step's graph (one replay per step, as with a
+        # single process); a capture the collective library refuses falls back to the two-graph shape
+        self.capture_collective = bool(capture_collective)
+        self.collective_captured = False
+        self.capture_note = ""
         self.loss = None
         # d(loss)/d(loss) = 1, kept resident: backward() would otherwise launch a fill for it every step
         self._one = torch.ones((), dtype=torch.float32, device=self.y.device)
@@ -93,8 +98,11 @@ class Trainer:
             self.opt.step()
 
     def capture(self):
-        """Capture forward+backward and the Adam update as two HIP graphs; the (tiny) gradient all-reduce
-        between them stays an ordinary RCCL call on the same stream."""
+        """Capture the step as HIP graphs.  One process: one graph.  Data parallel: forward+backward and the Adam
+        update as two graphs with the (tiny) gradient all-reduce an ordinary RCCL call on the same stream between
+        them - or, with ``capture_collective``, the all-reduce inside a single graph when the collective library
+        accepts being captured (checked by replaying it once against the eager collective; any refusal or mismatch
+        falls back to the two-graph shape and is recorded in ``capture_note``)."""
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -106,6 +114,10 @@ class Trainer:
         # stream, and reusing them would fork the captured backward over two streams (torch warns about it; the
         # forked replay was seen to feed stale gradients to the random-walk layer).
         self.loss = None
+        if self.world > 1 and self.capture_collective and not self.sync_before_all_reduce:
+            if self._capture_single_graph():
+                return
+        self.collective_captured = False
         self.g_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_fb, capture_error_mode=self.capture_error_mode):
             self.fwd_bwd()
@@ -116,8 +128,74 @@ class Trainer:
             with torch.cuda.graph(self.g_opt, capture_error_mode=self.capture_error_mode):
                 self._opt_step()
 
+    def _capture_single_graph(self) -> bool:
+        """forward+backward, all-reduce and update in one graph.  Returns False (with everything as it was before,
+        the reason in ``capture_note``) when the capture raises or when a replay does not leave the averaged
+        gradient in the bucket."""
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g, capture_error_mode=self.capture_error_mode):
+                self.fwd_bwd()
+                self.bucket.all_reduce()
+                self._opt_step()
+        except Exception as exc:                         # refused by the runtime or the collective library
+            self.capture_note = "all-reduce capture refused (%s: %s)" % (type(exc).__name__, str(exc)[:200])
+            torch.cuda.synchronize()
+            self.loss = None
+            return False
+        # one replay, then the same sum done eagerly: every rank must hold identical (averaged) gradients, so the
+        # spread of a checksum of the bucket over the ranks must be zero
+        g.replay()
+        torch.cuda.synchronize()
+        import torch.distributed as dist
+        probe = self.bucket.flat.double().sum().reshape(1)
+        lo, hi = probe.clone(), probe.clone()
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not bool(torch.isfinite(probe).all()) or float((hi - lo).abs()) > 1e-9 * max(1.0, float(hi.abs())):
+            self.capture_note = "captured all-reduce left different gradients on the ranks; two graphs instead"
+            self.loss = None
+            return False
+        self.g_fb, self.g_opt = g, None
+        self.collective_captured = True
+        self.capture_note = "all-reduce captured inside the step graph"
+        return True
+
     def step_graph(self):
         self.g_fb.replay()
-        if self.world > 1:
+        if self.world > 1 and not self.collective_captured:
             self._all_reduce()
             self.g_opt.replay()
+
+    def phase_times(self, steps: int = 30):
+        """Median device time (ms) of the phases of the replayed step, from events on the launch stream, and the
+        host time of a whole step: where a data-parallel step spends its time (forward+backward graph, gradient
+        all-reduce, optimiser graph, and what the host adds between them)."""
+        import time
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+        host = []
+        two = self.world > 1 and not self.collective_captured
+        for i in range(steps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ev[i][0].record()
+            self.g_fb.replay()
+            ev[i][1].record()
+            if two:
+                self._all_reduce()
+                ev[i][2].record()
+                self.g_opt.replay()
+            ev[i][3].record()
+            torch.cuda.synchronize()
+            host.append((time.perf_counter() - t0) * 1e3)
+
+        def med(v):
+            v = sorted(v)
+            return round(v[len(v) // 2], 4)
+        out = {"step_device_ms": med([e[0].elapsed_time(e[3]) for e in ev]), "step_host_sync_ms": med(host)}
+        if two:
+            out["fwd_bwd_graph_ms"] = med([e[0].elapsed_time(e[1]) for e in ev])
+            out["all_reduce_ms"] = med([e[1].elapsed_time(e[2]) for e in ev])
+            out["optimizer_graph_ms"] = med([e[2].elapsed_time(e[3]) for e in ev])
+        return out

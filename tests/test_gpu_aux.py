@@ -128,6 +128,32 @@ def test_graph_replay_trains_like_eager(world, dev):
         assert rel_err(pg.detach().cpu().numpy(), pe.detach().cpu().numpy()) < 1e-3
 
 
+def test_data_parallel_step_with_captured_collective_slot(dev):
+    """The data-parallel step with the all-reduce inside the step's graph (one replay per step): on one device
+    without a process group the collective is a no-op, which exercises the capture, its self-check and the replay;
+    the trajectory must be the one of the two-graph shape.  Also the per-phase timing used by the benchmark."""
+    c = GoldenCase("mutag_b0")
+    hp = dict(c.hp, dropout=0.0)
+    two, one = _trainer(c, hp, dev, world=2), _trainer(c, hp, dev, world=2, capture_collective=True)
+    two.capture()
+    one.capture()
+    assert one.collective_captured and one.g_opt is None and "captured" in one.capture_note
+    assert not two.collective_captured and two.g_opt is not None
+    for _ in range(4):
+        two.step_graph()
+        one.step_graph()
+    torch.cuda.synchronize()
+    # `one` ran one step more (the replay of its self-check)
+    two.step_graph()
+    torch.cuda.synchronize()
+    for pa, pb in zip(two.model.parameters(), one.model.parameters()):
+        assert torch.equal(pa, pb)
+    ph = two.phase_times(steps=5)
+    assert set(ph) == {"step_device_ms", "step_host_sync_ms", "fwd_bwd_graph_ms", "all_reduce_ms", "optimizer_graph_ms"}
+    assert all(v >= 0 for v in ph.values())
+    assert set(one.phase_times(steps=3)) == {"step_device_ms", "step_host_sync_ms"}
+
+
 def test_graph_replay_draws_fresh_dropout_masks(dev):
     """The dropout offset lives on the device: every replay of the captured step advances it."""
     c = GoldenCase("mutag_b0")
