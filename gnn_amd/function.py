@@ -39,6 +39,31 @@ def choose_stream_len(n_nodes: int, hidden_dim: int, n_hidden: int, size_hidden:
                                                 int(bool(backward))))
 
 
+def _plan(lib, st: GraphStructure, d: int, n_hidden: int, s: int, steps: int):
+    """Launch constants of one (batch structure, hyper-parameters) pair, computed once: stream lengths of the fused
+    kernels, their partial-sum buffer sizes, workspace size.  Batches are reused every epoch, so a training loop
+    finds them in the structure's cache from the second step on (seven host calls into the library less per step)."""
+    key = (d, n_hidden, s, steps)
+    plan = st.plans.get(key)
+    if plan is None:
+        n, g = st.n, st.n_graphs
+        sl_f = choose_stream_len(n, d, n_hidden, s, steps)
+        sl_b = choose_stream_len(n, d, n_hidden, s, steps, backward=True)
+        n_part = int(lib.rwk_fused_dz_partials_count(n, sl_b, d, n_hidden, s, steps))
+        plan = {
+            "stream_len": sl_f, "stream_len_b": sl_b,
+            "k_slots": int(lib.rwk_fused_k_partials_size(n, sl_f, g, n_hidden, steps)),
+            "n_part": n_part,
+            "dz_rows32": int(lib.rwk_reduce_rows_level1(n_part)) if n_part > 32 else n_part,
+            "ws": int(lib.rwk_fused_backward_workspace(n, d, n_hidden, s, steps)),
+            "stats_size": int(lib.rwk_head_stats_size(g, steps * n_hidden)),
+            "stats_blocks": int(lib.rwk_fused_reduce_stats_blocks(g)),
+            "spb_blocks": int(lib.rwk_spmm_project_backward_blocks(n)),
+        }
+        st.plans[key] = plan
+    return plan
+
+
 def _reduce_rows(lib, partials2d, stream):
     """Deterministic column sum of a (P, V) tensor."""
     p, v = partials2d.shape
@@ -104,9 +129,9 @@ class _RWKernelLayer(torch.autograd.Function):
                            "rwk_hidden_forward")
             for i in range(1, steps):
                 st.spmm(xs[i - 1], xs[i])                                        # model.py:55
-            stream_len = choose_stream_len(n, d, n_hidden, s, steps)
-            slots = lib.rwk_fused_k_partials_size(n, stream_len, g, n_hidden, steps)
-            k_partials = torch.empty(slots, dtype=torch.float32, device=dev)
+            plan = _plan(lib, st, d, n_hidden, s, steps)
+            stream_len = plan["stream_len"]
+            k_partials = torch.empty(plan["k_slots"], dtype=torch.float32, device=dev)
             _lib.check(lib.rwk_fused_forward(xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm),
                                              n, d, n_hidden, s, steps, stream_len, drop, _lib.ptr(rng_used),
                                              k_partials.data_ptr(), stream), "rwk_fused_forward")
@@ -114,14 +139,14 @@ class _RWKernelLayer(torch.autograd.Function):
             if handoff is not None and FUSED_STEP_LAUNCHES and steps * n_hidden <= 256:
                 # the head's batch statistics (and its draw of the generator state) ride in the K reduction
                 head_drop = bool(handoff.get("head_drop")) and rng_state is not None
-                stats = torch.empty(lib.rwk_head_stats_size(g, steps * n_hidden), dtype=torch.float32, device=dev)
+                stats = torch.empty(plan["stats_size"], dtype=torch.float32, device=dev)
                 rng_head = torch.empty(2, dtype=torch.int64, device=dev) if head_drop else None
                 _lib.check(lib.rwk_fused_reduce_stats(
                     k_partials.data_ptr(), st.seg_ptr.data_ptr(), st.counts_f32.data_ptr(), g, n_hidden, steps,
                     stream_len, drop, int(bool(normalize)), k.data_ptr(), stats.data_ptr(),
                     _lib.ptr(rng_state) if head_drop else None, _lib.ptr(rng_head), stream), "rwk_fused_reduce_stats")
                 handoff["stats"] = stats
-                handoff["n_stats"] = int(lib.rwk_fused_reduce_stats_blocks(g))
+                handoff["n_stats"] = plan["stats_blocks"]
                 handoff["rng_used"] = rng_head
             else:
                 _lib.check(lib.rwk_fused_reduce(k_partials.data_ptr(), st.seg_ptr.data_ptr(),
@@ -142,17 +167,18 @@ class _RWKernelLayer(torch.autograd.Function):
         steps, normalize, drop, projected = ctx.cfg
         _, n_hidden, s, d = z.shape
         n = st.n
-        stream_len = choose_stream_len(n, d, n_hidden, s, steps, backward=True)
+        plan = _plan(lib, st, d, n_hidden, s, steps)
+        stream_len = plan["stream_len_b"]
         dev = xs.device
         with _lib.device_guard(dev):
             stream = _lib.current_stream(dev)
             d_k = d_k.contiguous().float()
             dx = torch.empty_like(xs)
-            n_part = lib.rwk_fused_dz_partials_count(n, stream_len, d, n_hidden, s, steps)
+            n_part = plan["n_part"]
             if n_part <= 0:
                 raise NotImplementedError("unsupported hyper-parameters for the fused backward kernel")
             dz_partials = torch.empty((n_part, steps * n_hidden * s * d), dtype=torch.float32, device=dev)
-            ws_n = lib.rwk_fused_backward_workspace(n, d, n_hidden, s, steps)
+            ws_n = plan["ws"]
             ws = torch.empty(ws_n, dtype=torch.float32, device=dev) if ws_n else None
             _lib.check(lib.rwk_fused_backward(xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm),
                                               d_k.data_ptr(), st.counts_f32.data_ptr(), n, d, n_hidden, s, steps,
@@ -163,7 +189,7 @@ class _RWKernelLayer(torch.autograd.Function):
             # independent of the SpMM chain and rides in the first SpMM's launch when there is one.
             dz, dz_rows, job = dz_partials, n_part, None
             if n_part > 32:
-                dz_rows = lib.rwk_reduce_rows_level1(n_part)
+                dz_rows = plan["dz_rows32"]
                 dz = torch.empty((dz_rows, dz_partials.shape[1]), dtype=torch.float32, device=dev)
                 job = (dz_partials, dz)
             last = 1 if ctx.fuse_step else 0                                    # the fused launch does step 1 -> 0
@@ -179,7 +205,7 @@ class _RWKernelLayer(torch.autograd.Function):
             if ctx.fuse_step:
                 f = feats.shape[1]
                 csr_t = st.csr_t
-                blocks = lib.rwk_spmm_project_backward_blocks(n)
+                blocks = plan["spb_blocks"]
                 partials = torch.empty((blocks, d * f + d), dtype=torch.float32, device=dev)
                 d_inp = torch.empty_like(feats) if ctx.needs_input_grad[0] else None
                 red_in, red_out = job if job is not None else (None, None)

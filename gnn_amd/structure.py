@@ -83,6 +83,7 @@ class GraphStructure:
         self.seg_ptr = None      # int32 (G+1)
         self.counts = None       # int64 (G)  == torch.unique(..., return_counts=True)[1]
         self.counts_f32 = None   # float32 (G)
+        self.plans = {}          # launch constants per hyper-parameter set (gnn_amd.function._plan)
         self._keepalive = ()
 
     # ------------------------------------------------------------------------------------
