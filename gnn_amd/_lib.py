@@ -86,7 +86,7 @@ SIGNATURES = {
                                     _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rwk_head_train_supported": (c_int, [_I64, _I64, _I64, _I64]),
     "rwk_head_train_forward": (c_int, [_P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, c_float, c_float, _P, _I64, _P,
-                                       _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                       _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rwk_head_train_backward": (c_int, [_P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rwk_reduce_rows_workspace": (_I64, [_I64, _I64]),
     "rwk_reduce_rows": (c_int, [_P, _I64, _I64, _P, _P, _P]),

@@ -742,12 +742,15 @@ head_train_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
                   const float *__restrict__ w2, const float *__restrict__ b2, float drop_p,
                   const unsigned long long *__restrict__ rng, float *__restrict__ mean_out,
                   float *__restrict__ invstd_out, float *__restrict__ out, const long long *__restrict__ labels,
-                  float *__restrict__ loss_partials, float *__restrict__ dy, float *__restrict__ grad_partials) {
+                  float *__restrict__ loss_partials, float *__restrict__ dy, float *__restrict__ grad_partials,
+                  float *__restrict__ loss_pending) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int c = dm.c, p = dm.p, nc = dm.nc;
     const int cs = c + 1, ps = p + 1;
     const int nv = head_nv(c, p, nc);
     float nll = 0.f;
+    // the loss value is finished by the backward launch: until then it reads as not-a-number, never as stale memory
+    if (loss_pending != nullptr && blockIdx.x == 0 && threadIdx.x == 0) loss_pending[0] = __builtin_nanf("");
     float *s_w1 = lds;                       // [p][cs]
     float *s_w2 = s_w1 + p * cs;             // [nc][ps]
     float *s_b1 = s_w2 + nc * ps;            // [p]
@@ -1358,7 +1361,7 @@ int rwk_head_train_forward(const float *k, int64_t g, int64_t c, int64_t p, int6
                            float momentum, float eps, float *stats, int64_t n_stats_ready, const float *w1,
                            const float *b1, const float *w2, const float *b2, float drop_p, uint64_t *rng_state,
                            uint64_t *rng_used, float *mean_out, float *invstd_out, float *out, const int64_t *labels,
-                           float *loss_partials, float *dy, float *partials, rwk_stream_t stream_) {
+                           float *loss_partials, float *dy, float *partials, float *loss, rwk_stream_t stream_) {
     RWK_REQUIRE_PTR(k);
     RWK_REQUIRE_PTR(bn_w);
     RWK_REQUIRE_PTR(bn_b);
@@ -1399,7 +1402,7 @@ int rwk_head_train_forward(const float *k, int64_t g, int64_t c, int64_t p, int6
     hipLaunchKernelGGL(head_train_kernel, dim3(head_blocks(g)), dim3(kBlock), lds, stream, k, dm, bn_w, bn_b,
                        running_mean, running_var, (long long *)num_batches_tracked, momentum, eps,
                        (const float *)stats, n_stats, w1, b1, w2, b2, drop_p, (const unsigned long long *)rng_used,
-                       mean_out, invstd_out, out, (const long long *)labels, loss_partials, dy, partials);
+                       mean_out, invstd_out, out, (const long long *)labels, loss_partials, dy, partials, loss);
     RWK_LAUNCH_CHECK();
     return RWK_OK;
 }

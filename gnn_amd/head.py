@@ -204,7 +204,7 @@ class _FusedHeadLoss(torch.autograd.Function):
                     stats.data_ptr(), n_stats, w1c.data_ptr(), b1c.data_ptr(), w2c.data_ptr(), b2c.data_ptr(), drop,
                     _lib.ptr(rng_state) if (drop and not ready) else None, _lib.ptr(rng_used) if drop else None,
                     mean.data_ptr(), invstd.data_ptr(), out.data_ptr(), yc.data_ptr(), loss_partials.data_ptr(),
-                    dy.data_ptr(), partials.data_ptr(), stream), "rwk_head_train_forward")
+                    dy.data_ptr(), partials.data_ptr(), loss.data_ptr(), stream), "rwk_head_train_forward")
                 ctx.cfg = (training, drop, True)
                 ctx.save_for_backward(kc, bn_wc, mean, invstd, dy, partials, loss_partials, loss)
                 ctx.sizes = (p, nc)

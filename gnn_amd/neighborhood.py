@@ -10,17 +10,14 @@ transition matrix around it (``:109-250``) are not.
 """
 from __future__ import annotations
 
-from collections import OrderedDict
-
 import torch
 
 from .rwconv import _Propagate
-from .structure import GraphStructure
+from .structure import GraphStructure, IdentityCache
 
 __all__ = ["adjacency_structure", "neighborhood_encoding"]
 
-_CACHE: "OrderedDict[tuple, GraphStructure]" = OrderedDict()
-_CACHE_CAPACITY = 256
+_CACHE = IdentityCache(256)
 
 
 def adjacency_structure(edge_index: torch.Tensor, num_nodes: int) -> GraphStructure:
@@ -32,7 +29,6 @@ def adjacency_structure(edge_index: torch.Tensor, num_nodes: int) -> GraphStruct
     key = (edge_index.data_ptr(), edge_index.shape[1], edge_index._version, int(num_nodes), str(edge_index.device))
     st = _CACHE.get(key)
     if st is not None:
-        _CACHE.move_to_end(key)
         return st
     dev = edge_index.device
     valid = (edge_index[0] < num_nodes) & (edge_index[1] < num_nodes)          # :537-538
@@ -41,10 +37,7 @@ def adjacency_structure(edge_index: torch.Tensor, num_nodes: int) -> GraphStruct
         return None
     a = torch.sparse_coo_tensor(ei, torch.ones(ei.shape[1], device=dev), (num_nodes, num_nodes)).coalesce()
     st = GraphStructure.build(a, torch.zeros(num_nodes, dtype=torch.int64, device=dev))
-    st._keepalive = (edge_index,)
-    _CACHE[key] = st
-    while len(_CACHE) > _CACHE_CAPACITY:
-        _CACHE.popitem(last=False)
+    _CACHE.put(key, st, (edge_index,))
     return st
 
 

@@ -256,7 +256,7 @@ class RW_GNN(nn.Module):
         x = self.sigmoid(narrow_linear(x, self.fc.weight, self.fc.bias))     # :113
         steps = [x]
         for i in range(1, self.max_step):
-            steps.append(self.rw_layers[i - 1](steps[-1], edge_index))        # :128
+            steps.append(self.rw_layers[i - 1](steps[-1], edge_index, st))    # :128
         xs = torch.stack(steps)
         z = hidden_chain(self.adj_hidden, self.features_hidden, self.max_step)
         p = self.dropout.p if self.training else 0.0

@@ -11,19 +11,16 @@ per-hidden-node output layout (``:128-150``) is not.
 """
 from __future__ import annotations
 
-from collections import OrderedDict
-
 import torch
 import torch.nn as nn
 
 from . import _lib
 from .function import _reduce_rows
-from .structure import GraphStructure
+from .structure import GraphStructure, IdentityCache
 
 __all__ = ["RWConv", "propagation_structure", "propagate", "narrow_linear"]
 
-_CACHE: "OrderedDict[tuple, GraphStructure]" = OrderedDict()
-_CACHE_CAPACITY = 256
+_CACHE = IdentityCache(256)
 
 
 def propagation_structure(edge_index: torch.Tensor, num_nodes: int, batch: torch.Tensor = None) -> GraphStructure:
@@ -37,7 +34,6 @@ def propagation_structure(edge_index: torch.Tensor, num_nodes: int, batch: torch
            None if batch is None else (batch.data_ptr(), batch._version))
     st = _CACHE.get(key)
     if st is not None:
-        _CACHE.move_to_end(key)
         return st
     dev = edge_index.device
     loops = torch.arange(num_nodes, dtype=torch.int64, device=dev)
@@ -48,10 +44,7 @@ def propagation_structure(edge_index: torch.Tensor, num_nodes: int, batch: torch
     # row = target, column = source; duplicates of an edge add up, as the scatter-add of aggr='add' does
     m = torch.sparse_coo_tensor(torch.stack([dst, src]), deg_inv[src], (num_nodes, num_nodes)).coalesce()
     st = GraphStructure.build(m, batch if batch is not None else torch.zeros(num_nodes, dtype=torch.int64, device=dev))
-    st._keepalive = (edge_index, batch)
-    _CACHE[key] = st
-    while len(_CACHE) > _CACHE_CAPACITY:
-        _CACHE.popitem(last=False)
+    _CACHE.put(key, st, (edge_index, batch))
     return st
 
 
@@ -79,9 +72,11 @@ class _Propagate(torch.autograd.Function):
         return dx, None
 
 
-def propagate(x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
-    """``M x``: every node receives ``x[j] / deg[j]`` from each of its in-edges ``j -> i`` and from itself."""
-    return _Propagate.apply(x, propagation_structure(edge_index, x.shape[0]))
+def propagate(x: torch.Tensor, edge_index: torch.Tensor, structure: GraphStructure = None) -> torch.Tensor:
+    """``M x``: every node receives ``x[j] / deg[j]`` from each of its in-edges ``j -> i`` and from itself.
+    ``structure``: the :func:`propagation_structure` of ``edge_index`` when the caller has built it already."""
+    st = structure if structure is not None else propagation_structure(edge_index, x.shape[0])
+    return _Propagate.apply(x, st)
 
 
 class _NarrowLinear(torch.autograd.Function):
@@ -139,5 +134,5 @@ class RWConv(nn.Module):
         super().__init__()
         self.lin = nn.Linear(in_channels, out_channels)
 
-    def forward(self, x, edge_index):
-        return narrow_linear(propagate(x, edge_index), self.lin.weight, self.lin.bias)
+    def forward(self, x, edge_index, structure: GraphStructure = None):
+        return narrow_linear(propagate(x, edge_index, structure), self.lin.weight, self.lin.bias)

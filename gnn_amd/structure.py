@@ -84,7 +84,6 @@ class GraphStructure:
         self.counts = None       # int64 (G)  == torch.unique(..., return_counts=True)[1]
         self.counts_f32 = None   # float32 (G)
         self.plans = {}          # launch constants per hyper-parameter set (gnn_amd.function._plan)
-        self._keepalive = ()
 
     # ------------------------------------------------------------------------------------
     @staticmethod
@@ -266,8 +265,41 @@ class GraphStructure:
 # ----------------------------------------------------------------------------------------
 # cache keyed by tensor identity
 # ----------------------------------------------------------------------------------------
-_CACHE: "OrderedDict[tuple, GraphStructure]" = OrderedDict()
-_CACHE_CAPACITY = 512
+class IdentityCache:
+    """Structures keyed by the identity (data pointers, versions) of the tensors they were built from.
+
+    An entry lives as long as those tensors do: it holds no reference to them, and a finalizer on each of them drops
+    the entry when the tensor object is collected - so the batches of a finished cross-validation fold
+    (``rwgnn2/main.py:47-72`` builds new ones per fold) release their CSR arrays with them, and a data pointer cannot
+    be met again by another batch while its entry exists.  ``capacity`` bounds the number of entries as a backstop."""
+
+    def __init__(self, capacity: int):
+        self.capacity = capacity
+        self.entries: "OrderedDict[tuple, object]" = OrderedDict()
+
+    def get(self, key):
+        st = self.entries.get(key)
+        if st is not None:
+            self.entries.move_to_end(key)
+        return st
+
+    def put(self, key, st, owners):
+        import weakref
+        self.entries[key] = st
+        for t in owners:
+            if t is not None:
+                weakref.finalize(t, self.entries.pop, key, None)
+        while len(self.entries) > self.capacity:
+            self.entries.popitem(last=False)
+
+    def clear(self):
+        self.entries.clear()
+
+    def __len__(self):
+        return len(self.entries)
+
+
+_CACHE = IdentityCache(512)
 
 
 def _key(adj, graph_indicator):
@@ -277,20 +309,15 @@ def _key(adj, graph_indicator):
 
 
 def get_structure(adj, graph_indicator) -> GraphStructure:
-    """Cached :meth:`GraphStructure.build`.  The cache entry keeps the key tensors alive, so a
-    data pointer cannot be reused by another batch while its entry exists."""
+    """Cached :meth:`GraphStructure.build`; the entry is dropped when ``adj`` or ``graph_indicator`` is collected."""
     if isinstance(adj, GraphStructure):
         return adj
     key = _key(adj, graph_indicator)
     st = _CACHE.get(key)
     if st is not None:
-        _CACHE.move_to_end(key)
         return st
     st = GraphStructure.build(adj, graph_indicator)
-    st._keepalive = (adj, graph_indicator)
-    _CACHE[key] = st
-    while len(_CACHE) > _CACHE_CAPACITY:
-        _CACHE.popitem(last=False)
+    _CACHE.put(key, st, (adj, graph_indicator))
     return st
 
 

@@ -312,7 +312,8 @@ int rwk_head_apply_loss(const float *k, int64_t g, int64_t c, int64_t p, int64_t
  * d(loss) = 1.  n_stats_ready > 0: stats holds that many block partials (rwk_fused_reduce_stats) and rng_used the
  * drawn generator state; 0: the statistics launch runs first, as in rwk_head_forward.  rwk_head_train_backward is
  * the one launch of the backward pass: multiplies by d_loss[0], adds the partial rows in block order (grads, layout
- * of rwk_head_backward), forms d_k and finishes the mean loss.  Training mode only; rwk_head_train_supported says
+ * of rwk_head_backward), forms d_k and finishes the mean loss (`loss` of the forward call, when not NULL, is set to
+ * NaN until then).  Training mode only; rwk_head_train_supported says
  * whether the sizes fit (both passes share one LDS allocation). */
 int rwk_head_train_supported(int64_t g, int64_t c, int64_t p, int64_t nc);
 int rwk_head_train_forward(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
@@ -320,7 +321,7 @@ int rwk_head_train_forward(const float *k, int64_t g, int64_t c, int64_t p, int6
                            float momentum, float eps, float *stats, int64_t n_stats_ready, const float *w1,
                            const float *b1, const float *w2, const float *b2, float drop_p, uint64_t *rng_state,
                            uint64_t *rng_used, float *mean_out, float *invstd_out, float *out, const int64_t *labels,
-                           float *loss_partials, float *dy, float *partials, rwk_stream_t stream);
+                           float *loss_partials, float *dy, float *partials, float *loss, rwk_stream_t stream);
 int rwk_head_train_backward(const float *k, int64_t g, int64_t c, int64_t p, int64_t nc, const float *bn_w,
                             const float *mean, const float *invstd, const float *dy, const float *partials,
                             const float *d_loss, const float *loss_partials, float *loss, float *grads, float *d_k,

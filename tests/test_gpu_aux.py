@@ -188,3 +188,50 @@ def test_fused_cross_entropy_matches_torch(dev):
         (got * 1.7).backward()
         assert got.shape == () and abs(float(got) - float(ref)) <= 1e-5 * max(abs(float(ref)), 1e-3)
         assert rel_err(xd.grad.cpu().numpy(), x64.grad.numpy()) < 1e-5
+
+
+def test_structure_cache_entry_lives_as_long_as_its_tensors(dev):
+    """The per-batch structure is cached by tensor identity and released with the batch: a training script that
+    builds new batches for every fold does not accumulate the CSR arrays of the finished ones."""
+    import gc
+    from gnn_amd import get_structure
+    from gnn_amd.structure import _CACHE, _key
+    c = GoldenCase("mutag_b0")
+    adj, feats, gi, _ = c.torch_inputs(dev)
+    key = _key(adj, gi)
+    st = get_structure(adj, gi)
+    assert get_structure(adj, gi) is st and key in _CACHE.entries
+    del st, adj
+    gc.collect()
+    assert key not in _CACHE.entries
+    adj2, _, gi2, _ = c.torch_inputs(dev)
+    key2 = _key(adj2, gi2)
+    st2 = get_structure(adj2, gi2)
+    assert key2 in _CACHE.entries
+    del gi2
+    gc.collect()
+    assert key2 not in _CACHE.entries
+    assert st2.n == c.n_nodes
+
+
+def test_fused_loss_is_nan_until_backward_and_labels_are_checked(dev):
+    """model.forward_with_loss in training mode: the loss value is finished by the backward launch and reads NaN
+    (never stale memory) before it; a label outside [0, n_classes) raises as F.cross_entropy does."""
+    c = GoldenCase("mutag_b0")
+    tr = _trainer(c, dict(c.hp, dropout=0.2), dev)
+    m = tr.model
+    adj, feats, gi, y = c.torch_inputs(dev)
+    out, loss = m.forward_with_loss(adj, feats, gi, y)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(loss.detach()))
+    loss.backward()
+    torch.cuda.synchronize()
+    ref = F.cross_entropy(out.detach(), y)
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    bad = y.clone()
+    bad[3] = c.hp["n_classes"]
+    with pytest.raises(IndexError):
+        m.forward_with_loss(adj, feats, gi, bad)
+    bad[3] = -100
+    with pytest.raises(IndexError):
+        m.forward_with_loss(adj, feats, gi, bad)
