@@ -287,3 +287,42 @@ def test_model_forward_with_loss(dev):
     assert abs(float(loss_a) - float(loss_b)) < 1e-6 * abs(float(loss_a))
     for (name, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
         assert rel(pb.grad, pa.grad) < 2e-5, name
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.2])
+@pytest.mark.parametrize("with_loss", [False, True])
+def test_statistics_from_k_reduction_equal_head_statistics(dev, drop, with_loss):
+    """Training mode: the random-walk layer's K reduction hands the head its batch-statistics partials and draws the
+    head's dropout offset (one launch less).  Against the same model with that handoff switched off: the same
+    generator offsets, hence the same keep masks; K is the same bits, the statistics are merged from other row blocks,
+    so outputs, running statistics and gradients agree to float32 rounding of the batch-norm (1e-5 / 2e-4 relative)."""
+    import copy
+    from gnn_amd import RW_NN
+    from gnn_amd.synth import random_batch
+    b = random_batch(200, 10, 40, 2.5, seed=11)
+    adj, feats, gi, y = b.to_torch(dev)
+    torch.manual_seed(3)
+    ma = RW_NN(1, 3, 16, 5, 4, 32, False, 2, drop, dev).to(dev).train()
+    mb = copy.deepcopy(ma)
+    mb._head_handoff = lambda structure, drop_: None
+    res = []
+    for m in (ma, mb):
+        m.seed_dropout(123)
+        if with_loss:
+            out, loss = m.forward_with_loss(adj, feats, gi, y)
+        else:
+            out = m(adj, feats, gi)
+            loss = F.cross_entropy(out, y)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((out.detach(), float(loss), m._rng_state.clone() if drop else None))
+    assert ma._head_handoff(type("S", (), {"n_graphs": 200})(), drop) is not None
+    assert rel(res[0][0], res[1][0]) < 1e-5
+    assert abs(res[0][1] - res[1][1]) < 1e-5 * abs(res[1][1])
+    if drop:
+        assert torch.equal(res[0][2], res[1][2])          # both paths consumed the same number of draws
+    for (name, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert rel(pa.grad, pb.grad) < 2e-4, name
+    assert rel(ma.bn.running_mean, mb.bn.running_mean) < 1e-6
+    assert rel(ma.bn.running_var, mb.bn.running_var) < 1e-5
+    assert int(ma.bn.num_batches_tracked) == int(mb.bn.num_batches_tracked) == 1
