@@ -562,7 +562,7 @@ int rwk_fused_path(int64_t d, int64_t h, int64_t s, int64_t max_step) {
 int64_t rwk_fused_stream_len(int64_t n, int64_t d, int64_t h, int64_t s, int64_t max_step, int backward) {
     if (n <= 0 || d <= 0 || h <= 0 || s <= 0 || max_step <= 0) return 0;
     if (rwk_mfma::supported(d, h, s, max_step) && !rwk_reg::supported(d, h, s, max_step))
-        return rwk_mfma::stream_len(n, h);
+        return rwk_mfma::stream_len(n, h, backward != 0);
     return rwk_reg::stream_len(n, h, s, max_step, backward != 0);
 }
 

@@ -31,7 +31,7 @@ int64_t backward_blocks(int64_t n, int64_t stream_len);
 // floats of dx_partials the backward needs (0 when H <= 16)
 int64_t dx_partials_size(int64_t n, int64_t d, int64_t h, int64_t max_step);
 // positions per stream that fill the chip in whole rounds of resident workgroups
-int64_t stream_len(int64_t n, int64_t h);
+int64_t stream_len(int64_t n, int64_t h, bool backward);
 int forward(const Args &a);
 int backward(const Args &a);
 

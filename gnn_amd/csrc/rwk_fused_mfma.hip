@@ -57,6 +57,13 @@ __device__ inline unsigned long long keep_bits(const DropCfg &c, uint32_t node, 
     return bits;
 }
 
+// v if bit `bit` of kk is set, else +0: the bit is spread to a mask (one signed bit-field extract) and ANDed in - two
+// instructions and no trip through the condition register, against shift, and, compare, select.
+__device__ inline float keep_or_zero(float v, uint32_t kk, int bit) {
+    const int m = __builtin_amdgcn_sbfe((int)kk, bit, 1);
+    return __int_as_float(__float_as_int(v) & m);
+}
+
 // Rows are 16-byte aligned (hidden_dim is a multiple of 4 on this path): one 16-byte load per piece.  A piece
 // that starts beyond d is read from the row's last piece instead and must be masked by the caller.
 __device__ inline float4 load4_raw(const float *__restrict__ row, int d, int off) {
@@ -67,20 +74,56 @@ __device__ inline float4 load4(const float *__restrict__ row, int d, int off) {
     return off < d ? v : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// Z rows of hidden graphs [16*hb, 16*hb+16), all steps and hidden nodes, into LDS: [i][s][16][ZS]
+// Row layout of the 16-row operand tiles in LDS (Z rows of 16 hidden graphs, x rows of 16 nodes).
+// hidden_dim 49..64 (NT = 4): rows of 64 floats without padding, the 16-byte slot c of row r stored at slot
+// c ^ r.  The lane groups a ds_read_b128 is served in ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32:
+// one 16-byte slot of the 256-byte bank row per lane) then read 16 different slots when lane (q, col) reads slot
+// 4 tc + q of row col, and the scalar reads of [row 4q + r][16 tc + col] (32 lanes per group, 32 banks) fall on
+// 32 different banks.  With the 4-float row padding used for the narrower tiles, two lanes of every b128 group
+// share a slot (measured: half of the kernels' LDS cycles were bank conflicts).
+template <int NT>
+constexpr int row_stride() { return NT == 4 ? 64 : 16 * NT + 4; }
+template <int NT>
+__device__ inline int roff(int row, int f) {                  // float offset of element f of row `row` (0..15)
+    if constexpr (NT == 4) return row * 64 + ((((f >> 2) ^ row) & 15) << 2) + (f & 3);
+    else return row * (16 * NT + 4) + f;
+}
+// A 16 x 16 gradient tile G[node][hidden graph] of the pipelined backward kernel: node n in row 4 (n % 4) + n / 4,
+// the 16-byte slot c of that row at slot c ^ (n % 4).  Conflict-free for the 16-byte accesses of lane (q, col) to
+// G[col][4q..4q+3] and for the scalar reads of G[4q + r][col].
+__device__ inline int g_row(int n16) { return ((n16 & 3) << 2) | (n16 >> 2); }
+__device__ inline int goff(int n, int hgraph) {
+    return g_row(n) * 16 + ((((hgraph >> 2) ^ n) & 3) << 2) + (hgraph & 3);
+}
+
+// Z rows of hidden graphs [16*hb, 16*hb+16), all steps and hidden nodes, into LDS: [i][s][16 rows, see roff].  16-byte pieces
+// (hidden_dim is a multiple of 4 on this path), four of a thread's loads in flight at a time.
 template <int LT, int NT>
 __device__ inline void stage_z(const float *__restrict__ z, float *zs, int h, int s, int d, int hb, int block) {
-    constexpr int DPAD = 16 * NT, ZS = DPAD + 4;
-    const int total = LT * s * 16 * DPAD;
-    for (int idx = threadIdx.x; idx < total; idx += block) {
-        const int k = idx % DPAD;
-        int r = idx / DPAD;
-        const int hl = r % 16; r /= 16;
-        const int ss = r % s;
-        const int i = r / s;
-        const int hq = 16 * hb + hl;
-        const float v = z[(((size_t)i * h + (hq < h ? hq : h - 1)) * s + ss) * d + (k < d ? k : d - 1)];
-        zs[((i * s + ss) * 16 + hl) * ZS + k] = (hq < h && k < d) ? v : 0.f;
+    constexpr int DPAD = 16 * NT, ZS = row_stride<NT>(), PPR = DPAD / 4;         // pieces per row
+    const int total = LT * s * 16 * PPR;
+    for (int idx0 = threadIdx.x; idx0 < total; idx0 += 4 * block) {
+        float4 v[4];
+        int dst[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = idx0 + u * block;
+            const int ic = idx < total ? idx : total - 1;
+            const int k4 = ic % PPR;
+            int r = ic / PPR;
+            const int hl = r % 16; r /= 16;
+            const int ss = r % s;
+            const int i = r / s;
+            const int hq = 16 * hb + hl;
+            v[u] = load4_raw(z + (((size_t)i * h + (hq < h ? hq : h - 1)) * s + ss) * d, d, 4 * k4);
+            ok[u] = hq < h && 4 * k4 < d;
+            dst[u] = idx < total ? (i * s + ss) * 16 * ZS + roff<NT>(hl, 4 * k4) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (dst[u] >= 0)
+                *reinterpret_cast<float4 *>(zs + dst[u]) = ok[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -108,22 +151,35 @@ __device__ unsigned long long rwk_stamp_buf[8 * 8];
 #define RWK_STAMP_FLUSH()
 #endif
 
-#define RWK_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// pipelined kernel: elapsed cycles since the previous stamp go to bucket k; bucket 6 / 7 = whole kernel in
+// shader cycles / 100 MHz ticks
+#ifdef RWK_STAMP
+#define RWK_PSTAMP_DECL()                                                        \
+    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};                     \
+    unsigned long long st_last = __builtin_readcyclecounter();                   \
+    const unsigned long long st_c0 = st_last, st_rt0 = __builtin_amdgcn_s_memrealtime()
+#define RWK_PSTAMP(k)                                                            \
+    do {                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+        const unsigned long long now_ = __builtin_readcyclecounter();            \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+        st_sum[k] += now_ - st_last;                                             \
+        st_last = now_;                                                          \
+    } while (0)
+#define RWK_PSTAMP_FLUSH()                                                       \
+    do {                                                                         \
+        st_sum[6] = __builtin_readcyclecounter() - st_c0;                        \
+        st_sum[7] = __builtin_amdgcn_s_memrealtime() - st_rt0;                   \
+        if (blockIdx.x == 3 && blockIdx.y == 0 && (threadIdx.x & 63) == 0)       \
+            for (int k_ = 0; k_ < 8; ++k_) rwk_stamp_buf[(threadIdx.x >> 6) * 8 + k_] = st_sum[k_]; \
+    } while (0)
+#else
+#define RWK_PSTAMP_DECL()
+#define RWK_PSTAMP(k)
+#define RWK_PSTAMP_FLUSH()
+#endif
 
-// acc(16 h x 16 nodes) = Z_i[s] X_i^T for this lane's fragments: zrow points at Z_i[s][h = lane&15][0]
-template <int NT>
-__device__ inline f32x4 tile_zx(const float *zrow, int q, const float4 (&xv)[NT]) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int tc = 0; tc < NT; ++tc) {
-        const float4 a = *reinterpret_cast<const float4 *>(zrow + 16 * tc + 4 * q);
-        acc = RWK_MFMA(a.x, xv[tc].x, acc);
-        acc = RWK_MFMA(a.y, xv[tc].y, acc);
-        acc = RWK_MFMA(a.z, xv[tc].z, acc);
-        acc = RWK_MFMA(a.w, xv[tc].w, acc);
-    }
-    return acc;
-}
+#define RWK_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // ------------------------------------------------------------------------------------------------
 // forward
@@ -133,7 +189,7 @@ __global__ void __launch_bounds__(kFwdBlock)
 forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const int *__restrict__ gid,
                const int *__restrict__ perm, int n, int d, int h, int s, int stream_len, int n_calls, uint32_t t0,
                uint32_t t1, const unsigned long long *__restrict__ rng, float *__restrict__ k_partials) {
-    constexpr int DPAD = 16 * NT, ZS = DPAD + 4;
+    constexpr int ZS = row_stride<NT>();
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *zs = lds;
     const int hb = blockIdx.y;
@@ -200,6 +256,15 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
         for (int i = 0; i < LT; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) node_acc[i][r] = 0.f;
+        // The Z operands of a group of 4 LT MFMAs are requested one group ahead (two register sets, chosen by the
+        // group's parity at compile time): their LDS round trip passes under the previous group's MFMAs.
+        float4 za[2][LT];
+        auto load_za = [&](int ss, int tc, float4 (&dst)[LT]) {
+#pragma unroll
+            for (int i = 0; i < LT; ++i)
+                dst[i] = *reinterpret_cast<const float4 *>(zs + (i * s + ss) * 16 * ZS + roff<NT>(col, 16 * tc + 4 * q));
+        };
+        load_za(0, 0, za[0]);
         for (int ss = 0; ss < s; ++ss) {
             // the LT tiles advance together: a dependent MFMA issues after 40 cycles, an independent one after 32
             f32x4 tt[LT];
@@ -207,10 +272,11 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
             for (int i = 0; i < LT; ++i) tt[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int tc = 0; tc < NT; ++tc) {
-                float4 a[LT];
-#pragma unroll
-                for (int i = 0; i < LT; ++i)
-                    a[i] = *reinterpret_cast<const float4 *>(zs + ((i * s + ss) * 16 + col) * ZS + 16 * tc + 4 * q);
+                constexpr bool kEven = (NT & 1) == 0;         // then group tc of every hidden node has parity tc & 1
+                const int cur = kEven ? (tc & 1) : 0;
+                float4 (&a)[LT] = za[cur];
+                if (tc + 1 < NT) load_za(ss, tc + 1, za[cur ^ 1]);
+                else load_za(ss + 1 < s ? ss + 1 : ss, 0, za[cur ^ 1]);      // last one: a harmless repeat
 #pragma unroll
                 for (int i = 0; i < LT; ++i) tt[i] = RWK_MFMA(a[i].x, xv[i][tc].x, tt[i]);
 #pragma unroll
@@ -219,6 +285,10 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
                 for (int i = 0; i < LT; ++i) tt[i] = RWK_MFMA(a[i].z, xv[i][tc].z, tt[i]);
 #pragma unroll
                 for (int i = 0; i < LT; ++i) tt[i] = RWK_MFMA(a[i].w, xv[i][tc].w, tt[i]);
+                if (!kEven) {
+#pragma unroll
+                    for (int i = 0; i < LT; ++i) za[0][i] = za[1][i];
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -227,7 +297,7 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
 #pragma unroll
                 for (int i = 0; i < LT; ++i) {
                     float prod = tt[0][r] * tt[i][r];
-                    if (DROP) prod = ((kk >> i) & 1u) ? prod : 0.f;
+                    if (DROP) prod = keep_or_zero(prod, kk, i);
                     node_acc[i][r] += prod;
                 }
             }
@@ -267,7 +337,7 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                 int n, int d, int h, int s, int stream_len, int n_calls, float scale, int normalize, uint32_t t0,
                 uint32_t t1, const unsigned long long *__restrict__ rng, int n_hb, float *__restrict__ dx_out,
                 float *__restrict__ dz_partials) {
-    constexpr int DPAD = 16 * NT, ZS = DPAD + 4;
+    constexpr int DPAD = 16 * NT, ZS = row_stride<NT>();
     constexpr int ITEMS = LT * NT, IPW = (ITEMS + kBwdWaves - 1) / kBwdWaves;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *zs = lds;                                          // [LT][s][16][ZS]
@@ -397,7 +467,7 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                 o.y = keep ? v.y : 0.f;
                 o.z = keep ? v.z : 0.f;
                 o.w = keep ? v.w : 0.f;
-                *reinterpret_cast<float4 *>(xb + (i * 16 + row) * ZS + 4 * ch) = o;
+                *reinterpret_cast<float4 *>(xb + i * 16 * ZS + roff<NT>(row, 4 * ch)) = o;
             }
         }
         const int st_node = pre_node_ok ? pre_node : -1;
@@ -424,7 +494,7 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
             for (int i = 0; i < LT; ++i)
 #pragma unroll
                 for (int tc = 0; tc < NT; ++tc)
-                    xv[i][tc] = *reinterpret_cast<const float4 *>(xb + (i * 16 + col) * ZS + 16 * tc + 4 * q);
+                    xv[i][tc] = *reinterpret_cast<const float4 *>(xb + i * 16 * ZS + roff<NT>(col, 16 * tc + 4 * q));
             unsigned long long kb[4] = {0, 0, 0, 0};
             if (DROP) {
 #pragma unroll
@@ -445,7 +515,7 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                     float4 a[LT];
 #pragma unroll
                     for (int i = 0; i < LT; ++i)
-                        a[i] = *reinterpret_cast<const float4 *>(zs + ((i * s + ss) * 16 + col) * ZS + 16 * tc + 4 * q);
+                        a[i] = *reinterpret_cast<const float4 *>(zs + (i * s + ss) * 16 * ZS + roff<NT>(col, 16 * tc + 4 * q));
 #pragma unroll
                     for (int i = 0; i < LT; ++i) tt[i] = RWK_MFMA(a[i].x, xv[i][tc].x, tt[i]);
 #pragma unroll
@@ -500,7 +570,7 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                 const int i = item / NT, tc = item % NT;
                 float xq[4];                                  // B of dZ: X_i[node = 4q + r][16tc + col]
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xq[r] = xb[(i * 16 + 4 * q + r) * ZS + 16 * tc + col];
+                for (int r = 0; r < 4; ++r) xq[r] = xb[i * 16 * ZS + roff<NT>(4 * q + r, 16 * tc + col)];
                 int nd[4];                                    // nodes of the dX rows this lane will store
 #pragma unroll
                 for (int r = 0; r < 4; ++r) nd[r] = t_node[buf * 16 + 4 * q + r];
@@ -521,11 +591,11 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                 float zb[4], gb[4];
                 auto load_ops = [&](int ss, float4 &oga, float (&ozb)[4], float (&ogb)[4]) {
                     const float *gtile = gs + (i * s + ss) * 16 * kGS;
-                    const float *zrow = zs + ((i * s + ss) * 16 + 4 * q) * ZS + 16 * tc + col;
+                    const float *ztile = zs + (i * s + ss) * 16 * ZS;
                     oga = *reinterpret_cast<const float4 *>(gtile + col * kGS + 4 * q);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        ozb[r] = zrow[r * ZS];
+                        ozb[r] = ztile[roff<NT>(4 * q + r, 16 * tc + col)];
                         ogb[r] = gtile[(4 * q + r) * kGS + col];
                     }
                 };
@@ -588,11 +658,391 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     }   // hidden-graph blocks
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward, pipelined: the same phases, but phase A runs one position step ahead of phase B and the staging two
+// steps ahead, so a step has ONE barrier and a wavefront that waits (for LDS, for its turn on the matrix pipe)
+// leaves the pipe to wavefronts in the other phase:
+//
+//   interval t:   phase A(t+1) -> G tiles, buffer (t+1)&1      stage(t+2) -> x rows, buffer (t+2)%3; keep bits,
+//                 phase B(t)   <- G tiles, buffer t&1                        dK and node ids of step t+2
+//                 barrier;  global loads of step t+3 are issued (consumed by stage(t+3) an interval later)
+//
+// Costs LDS: three x-row buffers and two G buffers (G tiles without padding, see goff).  The staging of step t+2
+// stands before phase B: its loads have had all of phase A to arrive, and phase B's dX stores are not yet in the in-order
+// memory counter the wait for those loads looks at.
+// ------------------------------------------------------------------------------------------------
+
+template <int LT, int NT, bool DROP, bool PERM>
+__global__ void __launch_bounds__(kBwdBlock)
+backward_pipe_kernel(const float *__restrict__ x, const float *__restrict__ z, const int *__restrict__ gid,
+                     const int *__restrict__ perm, const float *__restrict__ d_k,
+                     const float *__restrict__ counts_f32, int n, int d, int h, int s, int stream_len, int n_calls,
+                     float scale, int normalize, uint32_t t0, uint32_t t1,
+                     const unsigned long long *__restrict__ rng, int n_hb, float *__restrict__ dx_out,
+                     float *__restrict__ dz_partials) {
+    constexpr int DPAD = 16 * NT, ZS = row_stride<NT>();
+    constexpr int ITEMS = LT * NT, IPW = (ITEMS + kBwdWaves - 1) / kBwdWaves;
+    constexpr int XB = LT * 16 * ZS;                          // floats of one x-row buffer
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *zs = lds;                                          // [LT][s][16][ZS]
+    float *xt = zs + LT * s * 16 * ZS;                        // [3][LT][16 nodes][ZS]
+    float *gs = xt + 3 * XB;                                  // [2][LT][s][16 rows][16 hidden graphs]
+    unsigned long long *kbits = reinterpret_cast<unsigned long long *>(gs + 2 * LT * s * 256);    // [2][256]
+    int *t_node = reinterpret_cast<int *>(kbits + 2 * 256);   // [3][16] (+ 16 unused)
+    // scaled dK [2][LT][16][16 slots] and keep bits [2][16][16 slots]: hidden graph hl in row g_row(hl), so that
+    // the reads of rows 4q + r by lane (q, col) spread over the banks
+    float *dks = reinterpret_cast<float *>(t_node + 64);
+    const int gs_buf = LT * s * 256;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, col = lane & 15;
+    DropCfg cfg;
+    if (DROP) cfg = load_cfg(rng, t0, t1);
+    const int lh = LT * h;
+    const size_t step_stride = (size_t)n * d;
+    int hq0 = 4 * q;
+
+    f32x4 dz[IPW][kSMax];
+    auto slot_first = [&](int slot) -> int {
+        const long long cs = (long long)(blockIdx.x * 16 + slot) * stream_len;
+        return cs < n ? (int)cs : 0;
+    };
+    auto slot_count = [&](int slot) -> int {
+        const long long cs = (long long)(blockIdx.x * 16 + slot) * stream_len;
+        if (cs >= n) return 0;
+        return (int)(cs + stream_len < n ? stream_len : n - cs);
+    };
+
+    constexpr int kChunks = LT * 16 * (DPAD / 4);             // 16-byte pieces of the x rows of one step
+    constexpr int kLoads = (kChunks + kBwdBlock - 1) / kBwdBlock;
+    // Everything fetched for a later step stays untouched in registers until that step is staged: any arithmetic
+    // on a loaded value (even a select) would make the wavefront wait for the load right where it was issued.
+    float4 pre[kLoads];
+    bool pre_ok[kLoads];
+    int x_first[kLoads], x_count[kLoads];
+    const float *x_base[kLoads];
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) {
+        const int idx = tid + k * kBwdBlock;
+        const int ch = idx % (DPAD / 4);
+        const int row = (idx / (DPAD / 4)) % 16;
+        const int i = (idx / (DPAD / 4) / 16) % LT;
+        x_first[k] = slot_first(row);
+        x_count[k] = idx < kChunks ? slot_count(row) : 0;
+        x_base[k] = x + i * step_stride + (4 * ch < d ? 4 * ch : d - 4);
+    }
+    // Thread tid < 256 serves the pair (slot tid & 15, hidden graph tid >> 4): node id for the keep bits and the
+    // dK entries of the slot's graph.  Graph ids are fetched one step ahead of the dK loads that depend on them.
+    const int my_slot = tid & 15, my_hl = tid >> 4;
+    int my_hq = my_hl;
+    int my_hqc = my_hq < h ? my_hq : h - 1;
+    int pre_node = 0;
+    bool pre_node_ok = false;
+    float pre_dk[LT], pre_cnt = 1.f;
+    bool pre_dk_ok = false;
+    int nxt_gid = 0;
+    bool nxt_gid_ok = false;
+    int gc_cur = 0;
+    bool gc_ok = false;
+    const int my_first = slot_first(my_slot), my_count = slot_count(my_slot);
+    // The keep bits of the 256 (slot, hidden graph) pairs of a step are drawn by four wavefronts, 64 pairs each
+    // (pair p: slot p & 15 = this thread's own slot, hidden graph p >> 4).  With more than 8 hidden nodes,
+    // wavefronts 0 and 1 carry two of them in phase A, i.e. SIMDs 0 and 1 three and SIMDs 2 and 3 two: the
+    // generator (about the cost of one hidden node's MFMAs per wavefront) then goes to wavefronts 2, 3, 6, 7, which
+    // evens out the SIMDs; otherwise one wavefront per SIMD.
+    int kb_pair = -1;
+    if (s > kBwdWaves) {
+        if (wave & 2) kb_pair = 64 * ((wave & 1) + 2 * (wave >> 2)) + lane;
+    } else if (wave < 4) {
+        kb_pair = tid;
+    }
+    int hb_cur = 0;
+    auto load_gid = [&](int t) {
+        nxt_gid_ok = t < my_count;
+        nxt_gid = gid[nxt_gid_ok ? my_first + t : 0];
+    };
+    auto prefetch = [&](int t) {
+#pragma unroll
+        for (int k = 0; k < kLoads; ++k) {
+            pre_ok[k] = t < x_count[k];
+            const int pc = pre_ok[k] ? x_first[k] + t : 0;
+            const int node = PERM ? perm[pc] : pc;
+            pre[k] = *reinterpret_cast<const float4 *>(x_base[k] + (size_t)node * d);
+        }
+        pre_node_ok = t < my_count;
+        const int pc = pre_node_ok ? my_first + t : 0;
+        pre_node = PERM ? perm[pc] : pc;
+        const int gc = gc_cur;                                // graph of my_slot at step t (fetched a step ago)
+        pre_dk_ok = gc_ok && my_hq < h && tid < 256;
+        if (normalize) pre_cnt = counts_f32[gc];
+#pragma unroll
+        for (int i = 0; i < LT; ++i) pre_dk[i] = d_k[(size_t)gc * lh + i * h + my_hqc];
+        load_gid(t + 1);
+    };
+    // what prefetch(t) fetched goes to LDS: x rows -> xb, node ids -> tn[16], keep bits and scaled dK -> parity par
+    auto stage = [&](float *xb, int *tn, int par) {
+#pragma unroll
+        for (int k = 0; k < kLoads; ++k) {
+            const int idx = tid + k * kBwdBlock;
+            if (idx < kChunks) {
+                const int ch = idx % (DPAD / 4);
+                const int row = (idx / (DPAD / 4)) % 16;
+                const int i = idx / (DPAD / 4) / 16;
+                const float4 v = pre[k];
+                const bool keep = pre_ok[k] && 4 * ch < d;
+                float4 o;
+                o.x = keep ? v.x : 0.f;
+                o.y = keep ? v.y : 0.f;
+                o.z = keep ? v.z : 0.f;
+                o.w = keep ? v.w : 0.f;
+                *reinterpret_cast<float4 *>(xb + i * 16 * ZS + roff<NT>(row, 4 * ch)) = o;
+            }
+        }
+        const int st_node = pre_node_ok ? pre_node : -1;
+        if (tid < 16) tn[tid] = st_node;
+        if (tid < 256) {
+            const float f = normalize ? scale / pre_cnt : scale;
+#pragma unroll
+            for (int i = 0; i < LT; ++i)
+                dks[((par * LT + i) * 16 + g_row(my_hl)) * 16 + my_slot] = pre_dk_ok ? pre_dk[i] * f : 0.f;
+        }
+        if (DROP && kb_pair >= 0)
+            kbits[par * 256 + g_row(kb_pair >> 4) * 16 + (kb_pair & 15)] = keep_bits(cfg, (uint32_t)(st_node >= 0 ? st_node : 0),
+                                                   (uint32_t)(16 * hb_cur + (kb_pair >> 4)), n_calls);
+        // the graph id that came with this fetch is the one the next prefetch's dK loads use
+        gc_cur = nxt_gid_ok ? nxt_gid : 0;
+        gc_ok = nxt_gid_ok;
+        asm volatile("" : "+v"(gc_cur));
+    };
+    // phase A of one step: G tiles of the hidden nodes wave, wave + 8, ... from the x rows in xb -> gbuf.
+    // The Z operands of a group of 4 LT MFMAs are requested one group ahead (two register sets, chosen by the
+    // group's parity at compile time), so that their LDS round trip passes under the previous group's MFMAs.
+    auto phase_a = [&](const float *xb, int par, float *gbuf) {
+        if (wave >= s) return;
+        float4 xv[LT][NT];                                    // B of the recompute: X_i[node = col][16tc + 4q ..]
+#pragma unroll
+        for (int i = 0; i < LT; ++i)
+#pragma unroll
+            for (int tc = 0; tc < NT; ++tc)
+                xv[i][tc] = *reinterpret_cast<const float4 *>(xb + i * 16 * ZS + roff<NT>(col, 16 * tc + 4 * q));
+        float4 za[2][LT];
+        auto load_za = [&](int ss, int tc, float4 (&dst)[LT]) {
+#pragma unroll
+            for (int i = 0; i < LT; ++i)
+                dst[i] = *reinterpret_cast<const float4 *>(zs + (i * s + ss) * 16 * ZS + roff<NT>(col, 16 * tc + 4 * q));
+        };
+        load_za(wave, 0, za[0]);
+        unsigned long long kb[4] = {0, 0, 0, 0};
+        if (DROP) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) kb[r] = kbits[par * 256 + (4 * r + q) * 16 + col];     // row g_row(4q + r)
+        }
+        float dp_cur[LT][4];                                  // scaled dK of (node col's graph, hidden graph 4q + r)
+#pragma unroll
+        for (int i = 0; i < LT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dp_cur[i][r] = dks[((par * LT + i) * 16 + 4 * r + q) * 16 + col];
+        for (int ss = wave; ss < s; ss += kBwdWaves) {
+            const int ss_next = ss + kBwdWaves < s ? ss + kBwdWaves : ss;       // last one: a harmless repeat
+            f32x4 tt[LT];
+#pragma unroll
+            for (int i = 0; i < LT; ++i) tt[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tc = 0; tc < NT; ++tc) {
+                constexpr bool kEven = (NT & 1) == 0;         // then group tc of every hidden node has parity tc & 1
+                const int cur = kEven ? (tc & 1) : 0;
+                float4 (&a)[LT] = za[cur];
+                if (tc + 1 < NT) load_za(ss, tc + 1, za[cur ^ 1]);
+                else load_za(ss_next, 0, za[cur ^ 1]);
+#pragma unroll
+                for (int i = 0; i < LT; ++i) tt[i] = RWK_MFMA(a[i].x, xv[i][tc].x, tt[i]);
+#pragma unroll
+                for (int i = 0; i < LT; ++i) tt[i] = RWK_MFMA(a[i].y, xv[i][tc].y, tt[i]);
+#pragma unroll
+                for (int i = 0; i < LT; ++i) tt[i] = RWK_MFMA(a[i].z, xv[i][tc].z, tt[i]);
+#pragma unroll
+                for (int i = 0; i < LT; ++i) tt[i] = RWK_MFMA(a[i].w, xv[i][tc].w, tt[i]);
+                if (!kEven) {
+#pragma unroll
+                    for (int i = 0; i < LT; ++i) za[0][i] = za[1][i];
+                }
+            }
+            float gt[LT][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                uint32_t kk = 0;
+                if (DROP) kk = (uint32_t)(kb[r] >> (ss * LT));
+                float w[LT];
+#pragma unroll
+                for (int i = 0; i < LT; ++i) {
+                    w[i] = dp_cur[i][r];
+                    if (DROP) w[i] = keep_or_zero(w[i], kk, i);
+                }
+                float a0 = 2.f * w[0] * tt[0][r];            // step 0 contributes keep * zx^2
+#pragma unroll
+                for (int i = 1; i < LT; ++i) {
+                    a0 = fmaf(w[i], tt[i][r], a0);
+                    gt[i][r] = w[i] * tt[0][r];
+                }
+                gt[0][r] = a0;
+            }
+#pragma unroll
+            for (int i = 0; i < LT; ++i)
+                *reinterpret_cast<float4 *>(gbuf + (i * s + ss) * 256 + goff(col, 4 * q)) =
+                    make_float4(gt[i][0], gt[i][1], gt[i][2], gt[i][3]);
+        }
+    };
+    // phase B of one step: dX rows stored, dZ accumulated
+    auto phase_b = [&](const float *xb, const int *tn, const float *gbuf, int hb) {
+#pragma unroll
+        for (int it = 0; it < IPW; ++it) {
+            const int item = wave + it * kBwdWaves;
+            if (item < ITEMS) {                               // wave-uniform
+                const int i = item / NT, tc = item % NT;
+                float xq[4];                                  // B of dZ: X_i[node = 4q + r][16tc + col]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xq[r] = xb[i * 16 * ZS + roff<NT>(4 * q + r, 16 * tc + col)];
+                int nd[4];                                    // nodes of the dX rows this lane will store
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nd[r] = tn[4 * q + r];
+                // dX so far (earlier blocks of hidden graphs): requested now, added after the MFMAs.  Agent-scope
+                // loads: the element was stored by this very lane, but a plain load could hit a stale L1 line.
+                const int kcol = 16 * tc + col < d ? 16 * tc + col : d - 1;
+                float old[4] = {0.f, 0.f, 0.f, 0.f};
+                if (hb > 0) {                                 // uniform
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        old[r] = __hip_atomic_load(dx_out + (size_t)i * step_stride +
+                                                       (size_t)(nd[r] >= 0 ? nd[r] : 0) * d + kcol,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                f32x4 dxa = {0.f, 0.f, 0.f, 0.f};
+                // operands of hidden node ss: ga = G_i[ss][node = col][h = 4q..4q+3] (A of dX),
+                // zb[r] = Z_i[ss][h = 4q + r][16tc + col] (B of dX), gb[r] = G_i[ss][node = 4q + r][h = col] (A of dZ)
+                // Two operand sets, chosen by the hidden node's parity at compile time: the set of hidden node
+                // ss + 1 is requested before the MFMAs of hidden node ss are issued and first touched after them.
+                struct Ops {
+                    float4 ga;
+                    float zb[4], gb[4];
+                };
+                Ops ops[2];
+                auto load_ops = [&](int ss, Ops &o) {
+                    const float *gtile = gbuf + (i * s + ss) * 256;
+                    const float *ztile = zs + (i * s + ss) * 16 * ZS;
+                    o.ga = *reinterpret_cast<const float4 *>(gtile + goff(col, 4 * q));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        o.zb[r] = ztile[roff<NT>(4 * q + r, 16 * tc + col)];
+                        o.gb[r] = gtile[goff(4 * q + r, col)];
+                    }
+                };
+                load_ops(0, ops[0]);
+#pragma unroll
+                for (int ss = 0; ss < kSMax; ++ss) {
+                    if (ss < s) {                             // uniform
+                        // after the last hidden node this reads what follows the tile in LDS: unused
+                        load_ops(ss + 1, ops[(ss + 1) & 1]);
+                        const Ops &o = ops[ss & 1];
+                        dxa = RWK_MFMA(o.ga.x, o.zb[0], dxa);
+                        dz[it][ss] = RWK_MFMA(o.gb[0], xq[0], dz[it][ss]);
+                        dxa = RWK_MFMA(o.ga.y, o.zb[1], dxa);
+                        dz[it][ss] = RWK_MFMA(o.gb[1], xq[1], dz[it][ss]);
+                        dxa = RWK_MFMA(o.ga.z, o.zb[2], dxa);
+                        dz[it][ss] = RWK_MFMA(o.gb[2], xq[2], dz[it][ss]);
+                        dxa = RWK_MFMA(o.ga.w, o.zb[3], dxa);
+                        dz[it][ss] = RWK_MFMA(o.gb[3], xq[3], dz[it][ss]);
+                    }
+                }
+                const int k = 16 * tc + col;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (nd[r] >= 0 && k < d)
+                        dx_out[(size_t)i * step_stride + (size_t)nd[r] * d + k] = old[r] + dxa[r];
+                }
+            }
+        }
+    };
+
+    RWK_PSTAMP_DECL();
+    // The blocks of 16 hidden graphs are taken one after the other by the same workgroup, so that their shares of
+    // dX are added in block order by the lane that owns the element (no partial copies, no second launch).
+    for (int hb = 0; hb < n_hb; ++hb) {
+        hq0 = 16 * hb + 4 * q;
+        hb_cur = hb;
+        my_hq = 16 * hb + my_hl;
+        my_hqc = my_hq < h ? my_hq : h - 1;
+        __syncthreads();                                      // readers of the previous block's LDS contents are done
+        stage_z<LT, NT>(z, zs, h, s, d, hb, kBwdBlock);
+#pragma unroll
+        for (int it = 0; it < IPW; ++it)
+#pragma unroll
+            for (int ss = 0; ss < kSMax; ++ss) dz[it][ss] = f32x4{0.f, 0.f, 0.f, 0.f};
+        load_gid(0);
+        gc_cur = nxt_gid_ok ? nxt_gid : 0;
+        gc_ok = nxt_gid_ok;
+        prefetch(0);
+        // x-row buffers in rotation: xa holds the step phase A works on, xb the one phase B works on, xs is filled
+        float *xs_ = xt, *xa_ = xt + XB, *xb_ = xt + 2 * XB;
+        int *ns_ = t_node, *na_ = t_node + 16, *nb_ = t_node + 32;
+        auto rotate = [&]() {
+            float *tx = xb_; xb_ = xa_; xa_ = xs_; xs_ = tx;
+            int *tn = nb_; nb_ = na_; na_ = ns_; ns_ = tn;
+        };
+        stage(xs_, ns_, 0);                                   // step 0
+        rotate();                                             // step 0 is phase A's
+        if (1 < stream_len) prefetch(1);
+        __syncthreads();                                      // Z rows and step 0 staged
+        phase_a(xa_, 0, gs);
+        if (1 < stream_len) stage(xs_, ns_, 1);               // step 1
+        rotate();                                             // step 0 is phase B's, step 1 phase A's
+        __syncthreads();
+        if (2 < stream_len) prefetch(2);
+        RWK_PSTAMP(5);
+        for (int t = 0; t < stream_len; ++t) {
+            const int par = t & 1;
+            if (t + 1 < stream_len) phase_a(xa_, par ^ 1, gs + (par ^ 1) * gs_buf);
+            RWK_PSTAMP(0);
+            if (t + 2 < stream_len) stage(xs_, ns_, par);
+            RWK_PSTAMP(1);
+            phase_b(xb_, nb_, gs + par * gs_buf, hb);
+            RWK_PSTAMP(2);
+            rotate();
+            __syncthreads();
+            RWK_PSTAMP(3);
+            if (t + 3 < stream_len) prefetch(t + 3);
+            RWK_PSTAMP(4);
+        }
+
+        // dZ: the lane holds dZ_i[ss][h = 4q + r][16tc + col] of its items
+        float *out = dz_partials + (size_t)blockIdx.x * LT * h * s * d;
+#pragma unroll
+        for (int it = 0; it < IPW; ++it) {
+            const int item = wave + it * kBwdWaves;
+            if (item >= ITEMS) continue;
+            const int i = item / NT, tc = item % NT;
+            const int k = 16 * tc + col;
+#pragma unroll
+            for (int ss = 0; ss < kSMax; ++ss) {
+                if (ss >= s) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int hq = hq0 + r;
+                    if (hq < h && k < d) out[(((size_t)i * h + hq) * s + ss) * d + k] = dz[it][ss][r];
+                }
+            }
+        }
+        RWK_PSTAMP(5);
+    }   // hidden-graph blocks
+    RWK_PSTAMP_FLUSH();
+}
+
 inline int nt_of(int d) { return (d + 15) / 16; }
 
-inline size_t fwd_lds(int l, int s, int nt) { return (size_t)l * s * 16 * (16 * nt + 4) * sizeof(float); }
+inline int row_stride_of(int nt) { return nt == 4 ? 64 : 16 * nt + 4; }
+inline size_t fwd_lds(int l, int s, int nt) { return (size_t)l * s * 16 * row_stride_of(nt) * sizeof(float); }
 inline size_t bwd_lds(int l, int s, int nt) {
-    const int dpad = 16 * nt, zs = dpad + 4;
+    const int zs = row_stride_of(nt);
     return ((size_t)l * s * 16 * zs + 2 * (size_t)l * 16 * zs + (size_t)l * s * 16 * kGS) * sizeof(float) +
            2 * 256 * sizeof(unsigned long long) + 32 * sizeof(int) + 2 * (size_t)l * 256 * sizeof(float);
 }
@@ -621,16 +1071,27 @@ int launch_fwd(const Args &a) {
     return RWK_OK;
 }
 
+inline size_t bwd_pipe_lds(int l, int s, int nt) {
+    const int zs = row_stride_of(nt);
+    return ((size_t)l * s * 16 * zs + 3 * (size_t)l * 16 * zs + 2 * (size_t)l * s * 256) * sizeof(float) +
+           2 * 256 * sizeof(unsigned long long) + 64 * sizeof(int) + 2 * (size_t)l * 256 * sizeof(float);
+}
+// the pipelined kernel when its buffers fit the 160 KB of LDS (with a little room left for the runtime)
+inline bool pipelined(int l, int s, int nt) { return bwd_pipe_lds(l, s, nt) + 256 <= 160 * 1024; }
+
 template <int LT, int NT>
 int launch_bwd(const Args &a) {
     const int hb = (a.h + 15) / 16;
     const dim3 grid((unsigned)backward_blocks(a.n, a.stream_len), 1u);
-    const size_t lds = bwd_lds(LT, a.s, NT);
+    const bool pipe = pipelined(LT, a.s, NT);
+    const size_t lds = pipe ? bwd_pipe_lds(LT, a.s, NT) : bwd_lds(LT, a.s, NT);
     const int n_calls = (a.s * a.max_step + 14) / 15;
     float *dx_target = a.dx;
 #define RWK_B(DROPV)                                                                                            \
     {                                                                                                           \
-        auto kern = a.perm ? backward_kernel<LT, NT, DROPV, true> : backward_kernel<LT, NT, DROPV, false>;     \
+        auto kern = pipe ? (a.perm ? backward_pipe_kernel<LT, NT, DROPV, true>                                  \
+                                   : backward_pipe_kernel<LT, NT, DROPV, false>)                                \
+                         : (a.perm ? backward_kernel<LT, NT, DROPV, true> : backward_kernel<LT, NT, DROPV, false>); \
         if (lds > 64 * 1024) {                                                                                  \
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                                (int)lds);                                                       \
@@ -687,7 +1148,16 @@ int64_t dx_partials_size(int64_t n, int64_t d, int64_t h, int64_t max_step) {
 // Forward workgroups hold 128 streams for one block of 16 hidden graphs, one workgroup per CU (the Z slab
 // takes most of the LDS): aim at m full rounds of 256 workgroups with about 16 positions per stream, and up
 // to 64 in very large batches, so that the per-workgroup dZ partial rows stay small next to the X rows read.
-int64_t stream_len(int64_t n, int64_t h) {
+// Backward workgroups hold 16 streams for all blocks of hidden graphs and pay a fixed price per block (Z rows to
+// LDS, pipeline fill, the dZ partial rows): m full rounds of 256 workgroups with 24 to 48 positions per stream.
+int64_t stream_len(int64_t n, int64_t h, bool bwd) {
+    if (bwd) {
+        const int64_t per_round = 16 * 256;
+        int64_t m = (n + per_round * 16) / (per_round * 32);
+        if (m < 1) m = 1;
+        const int64_t len = rwk_ceil_div(n, per_round * m);
+        return len < 4 ? 4 : len;
+    }
     const int64_t hb = (h + 15) / 16;
     const int64_t per_round = 128 * 256 / hb;
     int64_t target = n / (per_round * 4);

@@ -14,9 +14,10 @@ buf = (ctypes.c_uint64 * 64)()
 lib.rwk_debug_read_stamps.restype = ctypes.c_int
 print('rc', lib.rwk_debug_read_stamps(buf))
 a = np.array(list(buf), dtype=np.float64).reshape(8, 8)
-names = ['B-store..top', 'stage', 'S1 wait', 'prefetch issue', 'phase A', 'S2 wait', 'pin(vm wait)', 'phase B mfma']
-steps = 13
-print('cycles per step, per wavefront (rows) and segment')
+names = ['phase A', 'stage', 'phase B', 'barrier', 'prefetch', 'per-block', 'kernel cyc', 'kernel 10ns']
+steps = 26 * 4
+print('pipelined backward: cycles per position step, per wavefront (rows) and segment; block 3 (first round)')
 print(' ' * 8 + ' '.join(f'{n[:12]:>13s}' for n in names))
 for w in range(8):
-    print(f'wave {w}: ' + ' '.join(f'{a[w, k] / steps:13.0f}' for k in range(8)), ' total', round(a[w].sum() / steps))
+    print(f'wave {w}: ' + ' '.join(f'{a[w, k] / steps:13.0f}' for k in range(6)),
+          f' kernel {a[w, 6]:.0f} cycles in {a[w, 7] / 100:.1f} us = {a[w, 6] / a[w, 7] / 10:.3f} GHz')
