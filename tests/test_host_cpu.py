@@ -115,7 +115,9 @@ def test_stream_length_rule():
     assert choose_stream_len(103008, 4, 64, 5, 2) == 26
     # matrix-core kernels: 248 forward workgroups x 4 blocks of 16 hidden graphs
     assert choose_stream_len(103008, 64, 64, 10, 2) == 13
-    assert choose_stream_len(103008, 64, 64, 10, 2, backward=True) == 13
+    # backward: 16 streams per workgroup, all blocks of hidden graphs in one workgroup: one round of 252 workgroups
+    assert choose_stream_len(103008, 64, 64, 10, 2, backward=True) == 26
+    assert choose_stream_len(16 * 103008, 64, 64, 10, 2, backward=True) == 31       # 13 full rounds
     assert choose_stream_len(0, 4, 16, 5, 2) == 0
 
 def test_rwconv_oracle_against_dense_matrix():
