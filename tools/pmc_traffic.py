@@ -15,7 +15,8 @@ import json
 import sys
 
 CLASSES = (("spmm_csr_kernel", "spmm_csr"), ("spmm_tile_kernel", "spmm_csr"), ("::forward_kernel<", "fused_forward"),
-           ("::backward_kernel<", "fused_backward"), ("fused_forward_kernel", "fused_forward"),
+           ("::backward_kernel<", "fused_backward"), ("::backward_pipe_kernel<", "fused_backward"),
+           ("fused_forward_kernel", "fused_forward"),
            ("fused_backward_kernel", "fused_backward"), ("fused_reduce_kernel", "fused_reduce"),
            ("sum_blocks_kernel", "sum_blocks"))
 COPY_BYTES = 1 << 30
