@@ -15,9 +15,10 @@
 namespace {
 
 // Diagnostic build only (-DRWK_STAMP): cycle shares of the segments of head_apply_kernel (slots 0..7) and
-// head_bwd_tile_kernel (slots 8..15) for wavefront 0 of workgroup 1.
+// head_bwd_tile_kernel (slots 8..15) and
+// head_train_kernel (slots 16..31) for wavefront 0 of workgroup 1.
 #ifdef RWK_STAMP
-__device__ unsigned long long rwk_head_stamp_buf[16];
+__device__ unsigned long long rwk_head_stamp_buf[32];
 #define HEAD_STAMP_DECL() unsigned long long st_last = __builtin_readcyclecounter()
 #define HEAD_STAMP_AT(k)                                                               \
     do {                                                                               \
@@ -49,6 +50,11 @@ struct FastDiv {
     }
     __device__ inline int mod(int i) const { return i - div(i) * d; }
 };
+// (1 - momentum) * running + momentum * batch, with the rounding steps spelled out so that every kernel that
+// updates the running statistics produces the same bits (left to itself the compiler contracts either product)
+__device__ inline float running_update(float running, float batch, float momentum) {
+    return fmaf(momentum, batch, (1.f - momentum) * running);
+}
 constexpr int kMaxBlocks = 256;
 constexpr int kMaxC = 256, kMaxNC = 32, kMaxPC = 8192;
 constexpr uint32_t kHeadCall = 0xFFFFFFFFu;       // Philox counter word no other mask of the model uses
@@ -61,6 +67,7 @@ __host__ __device__ inline int head_blocks(long long g) {
 // Workgroups of the statistics launch.  Every workgroup of the apply launch merges all of their partials for
 // every column (a round trip to L2 per 64 of them and per 32 columns), so there are fewer of them than row
 // tiles: the statistics pass itself only reads K once more however it is cut.
+__host__ __device__ inline int stats_stride(int c) { return 4 + 2 * c; }   // floats per block partial
 constexpr int kMaxStatsBlocks = 64;
 constexpr int kMaxFusedStatsBlocks = 128;    // block partials the fused K reduction (kreduce_stats_kernel) leaves
 __host__ __device__ inline int head_stats_blocks(long long g) {
@@ -69,7 +76,8 @@ __host__ __device__ inline int head_stats_blocks(long long g) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// batch statistics: partials[b] = {count, mean[C], M2[C]} over the rows of block b's tiles
+// batch statistics: partials[b] = {count, 3 unused, mean[C], M2[C]} over the rows of block b's tiles (the padding
+// keeps the two vectors 16-byte aligned for widths that are multiples of four)
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
 head_stats_kernel(const float *__restrict__ k, long long g, int c, float *__restrict__ partials,
@@ -119,13 +127,13 @@ head_stats_kernel(const float *__restrict__ k, long long g, int c, float *__rest
     }
     red[tid] = lane_ok ? m2 : 0.f;
     __syncthreads();
-    float *out = partials + (size_t)blockIdx.x * (1 + 2 * c);
+    float *out = partials + (size_t)blockIdx.x * stats_stride(c);
     if (tid == 0) out[0] = (float)count;
     if (tid < c) {
         float s = 0.f;
         for (int q = 0; q < tpc; ++q) s += red[q * c + tid];
-        out[1 + tid] = s_mean[tid];
-        out[1 + c + tid] = s;
+        out[4 + tid] = s_mean[tid];
+        out[4 + c + tid] = s;
     }
 }
 
@@ -246,13 +254,13 @@ kreduce_stats_kernel(const float *__restrict__ k_partials, const int *__restrict
     }
     red[tid] = lane_ok ? m2 : 0.f;
     __syncthreads();
-    float *out = partials + (size_t)blockIdx.x * (1 + 2 * c);
+    float *out = partials + (size_t)blockIdx.x * stats_stride(c);
     if (tid == 0) out[0] = (float)count;
     if (tid < c) {
         float sacc = 0.f;
         for (int q = 0; q < tpc; ++q) sacc += red[q * c + tid];
-        out[1 + tid] = s_mean[tid];
-        out[1 + c + tid] = sacc;
+        out[4 + tid] = s_mean[tid];
+        out[4 + c + tid] = sacc;
     }
 }
 
@@ -269,10 +277,10 @@ struct StatsChunk {
 #pragma unroll
         for (int u = 0; u < kChunk; ++u) {
             const int b = b0 + 8 * u;
-            const float *p = partials + (size_t)(b < n_blocks ? b : n_blocks - 1) * (1 + 2 * c);
+            const float *p = partials + (size_t)(b < n_blocks ? b : n_blocks - 1) * stats_stride(c);
             n[u] = p[0];
-            mean[u] = p[1 + col];
-            m2[u] = p[1 + c + col];
+            mean[u] = p[4 + col];
+            m2[u] = p[4 + c + col];
             if (b >= n_blocks) {                          // counts as an empty block
                 n[u] = 0.f;
                 m2[u] = 0.f;
@@ -281,12 +289,9 @@ struct StatsChunk {
     }
 };
 
-__device__ inline float sum8(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    return v;
-}
+// total over an aligned group of 8 lanes, the same bits on each of them (partners at lane distance 1, 2, then the
+// other quad: data-parallel-primitive moves, no trip through LDS)
+__device__ inline float sum8(float v) { return rwk_group_sum(v, 8); }
 
 __device__ inline float merge_stats8(const float *__restrict__ partials, int n_blocks, int c, int col, int lane8,
                                      const StatsChunk &first, float *var) {
@@ -440,8 +445,8 @@ head_apply_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
             if (training && blockIdx.x == 0) {
                 // running estimates as torch.nn.BatchNorm1d keeps them: unbiased variance, momentum update
                 const float unbiased = dm.g > 1 ? var * ((float)dm.g / (float)(dm.g - 1)) : var;
-                running_mean[col] = (1.f - momentum) * rm + momentum * mean;
-                running_var[col] = (1.f - momentum) * rv + momentum * unbiased;
+                running_mean[col] = running_update(rm, mean, momentum);
+                running_var[col] = running_update(rv, unbiased, momentum);
                 if (col == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
             }
             const float invstd = 1.f / sqrtf(var + eps);
@@ -749,6 +754,7 @@ head_train_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
     const int cs = c + 1, ps = p + 1;
     const int nv = head_nv(c, p, nc);
     float nll = 0.f;
+    HEAD_STAMP_DECL();
     // the loss value is finished by the backward launch: until then it reads as not-a-number, never as stale memory
     if (loss_pending != nullptr && blockIdx.x == 0 && threadIdx.x == 0) loss_pending[0] = __builtin_nanf("");
     float *s_w1 = lds;                       // [p][cs]
@@ -768,6 +774,7 @@ head_train_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
     float *s_o = s_dp + kRows * ps;          // [kRows][nc]  logits
     float *s_dl = s_o + kRows * nc;          // [kRows][nc]  gradient of the logits
     float *s_g = s_dl + kRows * nc;          // [nv]
+    float *s_one = s_g + nv;                 // [1]   the constant 1.0f (second factor of the plain column sums)
     const int tid = threadIdx.x;
     const FastDiv by_c(c), by_p(p), by_nc(nc);
 
@@ -783,7 +790,22 @@ head_train_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
         const int nr = (int)(dm.g - r0 < kRows ? dm.g - r0 : kRows);
         r_k.load(k + r0 * c, nr * c, tid);
     }
+    // generator state and the first tile's labels: fetched with the parameters, so that neither costs a round trip of
+    // its own in the middle of the tile
+    const bool drop = drop_p > 0.f;
+    unsigned long long rng_seed = 0, rng_off = 0;
+    if (drop) {
+        rng_seed = rng[0];
+        rng_off = rng[1];
+    }
+    long long first_label = 0;
+    {
+        const long long r = (long long)blockIdx.x * kRows + tid;
+        if (tid < kRows && r < dm.g) first_label = labels[r];
+    }
     for (int i = tid; i < nv; i += kBlock) s_g[i] = 0.f;
+    if (tid == 0) s_one[0] = 1.f;
+    HEAD_STAMP_AT(25);
     const int lane8 = tid & 7;
     int c0 = 0;
     do {                                                      // uniform trip count: the shuffles need all lanes
@@ -792,19 +814,22 @@ head_train_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
         StatsChunk first;
         first.load(partials, n_partials, c, col, lane8);
         const float rm = running_mean[col], rv = running_var[col], ga = bn_w[col], be = bn_b[col];
+        HEAD_STAMP_AT(26);
         if (c0 == 0) {
             r_w1.store_rows(w1, p * c, by_c, cs, s_w1, tid);
             r_w2.store_rows(w2, nc * p, by_p, ps, s_w2, tid);
             r_b1.store_flat(b1, p, s_b1, tid);
             r_b2.store_flat(b2, nc, s_b2, tid);
         }
+        HEAD_STAMP_AT(27);
         float var;
         const float mean = merge_stats8(partials, n_partials, c, col, lane8, first, &var);
+        HEAD_STAMP_AT(28);
         if (lane8 == 0 && col_raw < c) {
             if (blockIdx.x == 0) {
                 const float unbiased = dm.g > 1 ? var * ((float)dm.g / (float)(dm.g - 1)) : var;
-                running_mean[col] = (1.f - momentum) * rm + momentum * mean;
-                running_var[col] = (1.f - momentum) * rv + momentum * unbiased;
+                running_mean[col] = running_update(rm, mean, momentum);
+                running_var[col] = running_update(rv, unbiased, momentum);
                 if (col == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
             }
             const float invstd = 1.f / sqrtf(var + eps);
@@ -822,13 +847,14 @@ head_train_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
         }
         c0 += kBlock / 8;
     } while (c0 < c);
+    HEAD_STAMP_AT(29);
     __syncthreads();
+    HEAD_STAMP_AT(16);
 
-    const bool drop = drop_p > 0.f;
     uint32_t seed_lo = 0, key_hi = 0, off_lo = 0, keep_thr = 0xFFFFFFFFu;
     float keep_scale = 1.f;
     if (drop) {
-        const unsigned long long seed = rng[0], off = rng[1];
+        const unsigned long long seed = rng_seed, off = rng_off;
         seed_lo = (uint32_t)seed;
         key_hi = (uint32_t)(seed >> 32) ^ (uint32_t)(off >> 32);
         off_lo = (uint32_t)off;
@@ -845,6 +871,11 @@ head_train_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
         const long long r0 = t * kRows;
         const int nr = (int)(dm.g - r0 < kRows ? dm.g - r0 : kRows);
         const bool first_tile = t == blockIdx.x;
+        if (nr < kRows) {                                     // uniform: the parameter sums below run over all kRows rows
+            for (int i = tid + nr * cs; i < kRows * cs; i += kBlock) s_y[i] = s_xh[i] = 0.f;
+            for (int i = tid + nr * ps; i < kRows * ps; i += kBlock) s_h[i] = s_dp[i] = 0.f;
+            for (int i = tid + nr * nc; i < kRows * nc; i += kBlock) s_dl[i] = 0.f;
+        }
         // ---- forward (head_apply_kernel) ----
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -862,6 +893,7 @@ head_train_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
             s_xh[r * cs + col] = (kv - s_mu[col]) * s_is[col];
         }
         __syncthreads();
+        HEAD_STAMP_AT(17);
         for (int i = tid; i < nr * p; i += kBlock) {
             const int r = by_p.div(i), j = i - r * p;
             float acc = s_b1[j];
@@ -878,6 +910,7 @@ head_train_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
             s_h[r * ps + j] = acc;
         }
         __syncthreads();
+        HEAD_STAMP_AT(18);
         for (int i = tid; i < nr * nc; i += kBlock) {
             const int r = by_nc.div(i), q = i - r * nc;
             float acc = s_b2[q];
@@ -887,6 +920,7 @@ head_train_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
             s_o[r * nc + q] = acc;
         }
         __syncthreads();
+        HEAD_STAMP_AT(19);
         if (tid < nr) {
             float *o = s_o + tid * nc;
             float mx = o[0];
@@ -900,7 +934,7 @@ head_train_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
             }
             // cross-entropy of the stored log-probabilities and its gradient (head_bwd_tile_kernel, d_loss = 1)
             const float lse2 = row_lse(o, nc);
-            long long cls = labels[r0 + tid];
+            long long cls = first_tile ? first_label : labels[r0 + tid];
             cls = cls < 0 ? 0 : (cls >= nc ? nc - 1 : cls);  // the host side has checked the range (see head.py)
             nll += lse2 - o[cls];
             float sgo = 0.f;
@@ -911,6 +945,7 @@ head_train_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
             }
         }
         __syncthreads();
+        HEAD_STAMP_AT(20);
         // ---- backward, per-tile part (head_bwd_tile_kernel) ----
         for (int i = tid; i < nr * p; i += kBlock) {
             const int r = by_p.div(i), j = i - r * p;
@@ -920,6 +955,7 @@ head_train_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
             s_dp[r * ps + j] = s_h[r * ps + j] > 0.f ? acc * keep_scale : 0.f;
         }
         __syncthreads();
+        HEAD_STAMP_AT(21);
         for (int i = tid; i < nr * c; i += kBlock) {
             const int r = by_c.div(i), col = i - r * c;
             float acc = 0.f;
@@ -929,37 +965,57 @@ head_train_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
             dy[(r0 + r) * c + col] = acc;
         }
         __syncthreads();
-        for (int e = tid; e < nv; e += kBlock) {
-            float acc = 0.f;
-            if (e < o_b2) {
-                const int q = by_p.div(e), j = e - q * p;
-#pragma unroll 8
-                for (int r = 0; r < nr; ++r) acc = fmaf(s_dl[r * nc + q], s_h[r * ps + j], acc);
-            } else if (e < o_w1) {
-                const int q = e - o_b2;
-#pragma unroll 8
-                for (int r = 0; r < nr; ++r) acc += s_dl[r * nc + q];
-            } else if (e < o_b1) {
-                const int j = by_c.div(e - o_w1), col = (e - o_w1) - j * c;
-                const float ga = s_ga[col], be = s_be[col];
-#pragma unroll 8
-                for (int r = 0; r < nr; ++r) acc = fmaf(s_dp[r * ps + j], fmaf(s_xh[r * cs + col], ga, be), acc);
-            } else if (e < o_ga) {
-                const int j = e - o_b1;
-#pragma unroll 8
-                for (int r = 0; r < nr; ++r) acc += s_dp[r * ps + j];
-            } else if (e < o_be) {
-                const int col = e - o_ga;
-#pragma unroll 8
-                for (int r = 0; r < nr; ++r) acc = fmaf(s_y[r * cs + col], s_xh[r * cs + col], acc);
-            } else {
-                const int col = e - o_be;
-#pragma unroll 8
-                for (int r = 0; r < nr; ++r) acc += s_y[r * cs + col];
+        HEAD_STAMP_AT(22);
+        // this tile's share of the parameter sums.  Every element is sum_r A[r] * (B[r] * ga + be) over the tile's rows
+        // (plain column sums take B = 1): four elements at a time, their 64 LDS reads in flight together, rows in order.
+        for (int e0 = tid; e0 < nv; e0 += 4 * kBlock) {
+            // operands as offsets into the workgroup's LDS block (pointers chosen at run time among several arrays
+            // would lose their address space and be read through the flat path)
+            int oa[4], ob[4], sa[4], sb[4];
+            float ga4[4], be4[4], acc[4];
+            const int f_dl = (int)(s_dl - lds), f_h = (int)(s_h - lds), f_one = (int)(s_one - lds),
+                      f_dp = (int)(s_dp - lds), f_xh = (int)(s_xh - lds), f_y = (int)(s_y - lds);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e_raw = e0 + u * kBlock;
+                const int e = e_raw < nv ? e_raw : nv - 1;
+                ga4[u] = 1.f; be4[u] = 0.f; acc[u] = 0.f;
+                if (e < o_b2) {                               // d w2[q][j] = sum_r dl[r][q] h[r][j]
+                    const int q = by_p.div(e), j = e - q * p;
+                    oa[u] = f_dl + q; sa[u] = nc; ob[u] = f_h + j; sb[u] = ps;
+                } else if (e < o_w1) {                        // d b2[q]
+                    oa[u] = f_dl + (e - o_b2); sa[u] = nc; ob[u] = f_one; sb[u] = 0;
+                } else if (e < o_b1) {                        // d w1[j][col] = sum_r dp[r][j] y[r][col]
+                    const int j = by_c.div(e - o_w1), col = (e - o_w1) - j * c;
+                    oa[u] = f_dp + j; sa[u] = ps; ob[u] = f_xh + col; sb[u] = cs;
+                    ga4[u] = s_ga[col]; be4[u] = s_be[col];
+                } else if (e < o_ga) {                        // d b1[j]
+                    oa[u] = f_dp + (e - o_b1); sa[u] = ps; ob[u] = f_one; sb[u] = 0;
+                } else if (e < o_be) {                        // d gamma[col] = sum_r dY[r][col] xhat[r][col]
+                    const int col = e - o_ga;
+                    oa[u] = f_y + col; sa[u] = cs; ob[u] = f_xh + col; sb[u] = cs;
+                } else {                                      // d beta[col]
+                    oa[u] = f_y + (e - o_be); sa[u] = cs; ob[u] = f_one; sb[u] = 0;
+                }
             }
-            s_g[e] += acc;
+            float av[4][kRows], bv[4][kRows];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < kRows; ++r) {
+                    av[u][r] = lds[oa[u] + r * sa[u]];
+                    bv[u][r] = lds[ob[u] + r * sb[u]];
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int r = 0; r < kRows; ++r) acc[u] = fmaf(av[u][r], fmaf(bv[u][r], ga4[u], be4[u]), acc[u]);
+                const int e = e0 + u * kBlock;
+                if (e < nv) s_g[e] += acc[u];
+            }
         }
         __syncthreads();
+        HEAD_STAMP_AT(23);
     }
     float *dst = grad_partials + (size_t)blockIdx.x * nv;
     for (int e = tid; e < nv; e += kBlock) dst[e] = s_g[e];
@@ -970,6 +1026,388 @@ head_train_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
         for (int r = 0; r < kRows; ++r) acc += s_o[r];
         loss_partials[blockIdx.x] = acc;
     }
+    HEAD_STAMP_AT(24);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// training step at the reference's default widths (32 features = 16 hidden graphs x 2 steps, penultimate_dim 32,
+// at most kT32MaxNC classes): one wavefront per tile of 8 rows and no barrier-separated phases.
+//
+// head_train_kernel above spends its time between phases (nine barriers per tile, every operand through LDS and a
+// run-time index split per element: 31 k cycles for 8 x 32 x 32 multiply-adds each way).  Here lane (r, s) =
+// (l >> 3, l & 7) owns columns 4s..4s+3 of row r of the tile and keeps in registers the two slices of fc1's weight
+// it needs (all 32 rows x its 4 columns for the forward product, its 4 rows x all 32 columns for dY), the row's
+// values travel between lanes by data-parallel-primitive moves, and only the sums over the tile's rows go through
+// LDS (after one wait, no barrier: a workgroup is one wavefront).  Same expressions as head_train_kernel; the inner
+// products are added in another (fixed) order: per lane over its 4 columns, then over the 8 lanes.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kT32 = 32, kT32MaxNC = 4, kT32Threads = 64;
+
+// Sums of 32 per-lane values over the 8 lanes of an aligned group, scattered: lane s ends with the totals of values
+// 4s..4s+3.  Three halving steps - partner 7-s, then 3-s within the quad, then s^1 - in each of which a lane keeps
+// the half its final values lie in and adds the partner's copy of that half: 28 additions for 32 sums.
+__device__ inline void reduce_scatter8(const float (&v)[32], int s, float (&out)[4]) {
+    const bool up_a = s >= 4, up_b = (s & 3) >= 2, up_c = (s & 1) != 0;
+    float a[16], b[8];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const float keep = up_a ? v[m + 16] : v[m], give = up_a ? v[m] : v[m + 16];
+        a[m] = keep + rwk_dpp<0x141>(give);              // row_half_mirror
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const float keep = up_b ? a[m + 8] : a[m], give = up_b ? a[m] : a[m + 8];
+        b[m] = keep + rwk_dpp<0x1B>(give);               // quad_perm [3,2,1,0]
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const float keep = up_c ? b[m + 4] : b[m], give = up_c ? b[m] : b[m + 4];
+        out[m] = keep + rwk_dpp<0xB1>(give);             // quad_perm [1,0,3,2]
+    }
+}
+
+// total over the 8 lanes that share l & 7 (lane distances 8, 16, 32), the same bits on each of them
+__device__ inline float sum_rows8(float v) {
+    v += rwk_dpp<0x128>(v);                              // row_ror:8: lane l ^ 8 of the 16-lane row
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+__device__ inline float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+__global__ void __launch_bounds__(kT32Threads)
+head_train32_kernel(const float *__restrict__ k, HeadDims dm, const float *__restrict__ bn_w,
+                    const float *__restrict__ bn_b, float *running_mean, float *running_var,
+                    long long *num_batches_tracked, float momentum, float eps, const float *__restrict__ partials,
+                    int n_partials, const float *__restrict__ w1, const float *__restrict__ b1,
+                    const float *__restrict__ w2, const float *__restrict__ b2, float drop_p,
+                    const unsigned long long *__restrict__ rng, float *__restrict__ mean_out,
+                    float *__restrict__ invstd_out, float *__restrict__ out, const long long *__restrict__ labels,
+                    float *__restrict__ loss_partials, float *__restrict__ dy, float *__restrict__ grad_partials,
+                    float *__restrict__ loss_pending) {
+    constexpr int C = kT32, P = kT32, NCM = kT32MaxNC;
+    __shared__ __attribute__((aligned(16))) float s_dl[kRows][NCM], s_h[kRows][P], s_dp[kRows][P], s_dyt[kRows][C],
+        s_xh[kRows][C];
+    const int nc = dm.nc;
+    const int l = threadIdx.x, r = l >> 3, s = l & 7;
+    if (loss_pending != nullptr && blockIdx.x == 0 && l == 0) loss_pending[0] = __builtin_nanf("");
+    const long long n_tiles = (dm.g + kRows - 1) / kRows;
+
+    // ---- everything the first tile needs, requested before the first wait ----
+    long long t = blockIdx.x;
+    long long row = t * kRows + r;
+    bool valid = row < dm.g;
+    float4 kv = ld4(k + (valid ? row : dm.g - 1) * C + 4 * s);
+    long long label = labels[valid ? row : dm.g - 1];
+    const bool drop = drop_p > 0.f;
+    unsigned long long rng_seed = 0, rng_off = 0;
+    if (drop) {
+        rng_seed = rng[0];
+        rng_off = rng[1];
+    }
+    // batch statistics: lane (r, s) adds blocks r, r + 8, ... for its 4 columns
+    constexpr int kSB = kMaxFusedStatsBlocks / 8;        // blocks per lane at most
+    float sn_b[kSB];
+    float4 mean_b[kSB], m2_b[kSB];
+    const int stride = stats_stride(C);
+#pragma unroll
+    for (int u = 0; u < kSB; ++u) {
+        const int b = r + 8 * u;
+        const float *pb = partials + (size_t)(b < n_partials ? b : n_partials - 1) * stride;
+        sn_b[u] = pb[0];
+        mean_b[u] = ld4(pb + 4 + 4 * s);
+        m2_b[u] = ld4(pb + 4 + C + 4 * s);
+    }
+    const float4 gav = ld4(bn_w + 4 * s), bev = ld4(bn_b + 4 * s), rmv = ld4(running_mean + 4 * s),
+                 rvv = ld4(running_var + 4 * s);
+    float4 wf[P];                                        // fc1.weight[j][4s..4s+3], all j
+#pragma unroll
+    for (int j = 0; j < P; ++j) wf[j] = ld4(w1 + j * C + 4 * s);
+    float4 wb[4][C / 4];                                 // fc1.weight[4s + jj][:]
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int cg = 0; cg < C / 4; ++cg) wb[jj][cg] = ld4(w1 + (4 * s + jj) * C + 4 * cg);
+    const float4 b1v = ld4(b1 + 4 * s);
+    const float ga_c = bn_w[l & 31], be_c = bn_b[l & 31];      // for the parameter sums: column l & 31
+    float4 w2v[NCM];
+    float b2v[NCM];
+#pragma unroll
+    for (int q = 0; q < NCM; ++q) {
+        const int qc = q < nc ? q : nc - 1;
+        w2v[q] = ld4(w2 + qc * P + 4 * s);
+        b2v[q] = b2[qc];
+    }
+
+    // ---- batch statistics (merge_stats8's additions: blocks in order per lane, then the same butterfly) ----
+    float sn = 0.f;
+    float sm[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < kSB; ++u) {
+        const bool ok = r + 8 * u < n_partials;
+        const float nb = ok ? sn_b[u] : 0.f;
+        sn_b[u] = nb;
+        sn += nb;
+        sm[0] = fmaf(nb, mean_b[u].x, sm[0]);
+        sm[1] = fmaf(nb, mean_b[u].y, sm[1]);
+        sm[2] = fmaf(nb, mean_b[u].z, sm[2]);
+        sm[3] = fmaf(nb, mean_b[u].w, sm[3]);
+        if (!ok) m2_b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    sn = sum_rows8(sn);
+    float mean[4], var[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sm[e] = sum_rows8(sm[e]);
+        mean[e] = sn > 0.f ? sm[e] / sn : 0.f;
+    }
+    {
+        float qq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < kSB; ++u) {
+            const float mb[4] = {mean_b[u].x, mean_b[u].y, mean_b[u].z, mean_b[u].w};
+            const float m2[4] = {m2_b[u].x, m2_b[u].y, m2_b[u].z, m2_b[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dv = mb[e] - mean[e];
+                qq[e] += fmaf(sn_b[u] * dv, dv, m2[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            qq[e] = sum_rows8(qq[e]);
+            var[e] = sn > 0.f ? qq[e] / sn : 0.f;
+        }
+    }
+    const float ga[4] = {gav.x, gav.y, gav.z, gav.w}, be[4] = {bev.x, bev.y, bev.z, bev.w};
+    float invstd[4], sc[4], shift[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        invstd[e] = 1.f / sqrtf(var[e] + eps);
+        sc[e] = ga[e] * invstd[e];
+        shift[e] = be[e] - mean[e] * sc[e];
+    }
+    if (blockIdx.x == 0 && r == 0) {
+        const float rm[4] = {rmv.x, rmv.y, rmv.z, rmv.w}, rv[4] = {rvv.x, rvv.y, rvv.z, rvv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float unbiased = dm.g > 1 ? var[e] * ((float)dm.g / (float)(dm.g - 1)) : var[e];
+            running_mean[4 * s + e] = running_update(rm[e], mean[e], momentum);
+            running_var[4 * s + e] = running_update(rv[e], unbiased, momentum);
+            mean_out[4 * s + e] = mean[e];
+            invstd_out[4 * s + e] = invstd[e];
+        }
+        if (s == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
+    }
+
+    uint32_t seed_lo = 0, key_hi = 0, off_lo = 0, keep_thr = 0xFFFFFFFFu;
+    float keep_scale = 1.f;
+    if (drop) {
+        seed_lo = (uint32_t)rng_seed;
+        key_hi = (uint32_t)(rng_seed >> 32) ^ (uint32_t)(rng_off >> 32);
+        off_lo = (uint32_t)rng_off;
+        const double q = 1.0 - (double)drop_p;
+        const double thr = q * 4294967296.0;
+        keep_thr = thr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)thr;
+        keep_scale = 1.f / (1.f - drop_p);
+    }
+    const float inv_g = 1.f / (float)dm.g;
+    const int o_b2 = nc * P, o_w1 = o_b2 + nc, o_b1 = o_w1 + P * C, o_ga = o_b1 + P, o_be = o_ga + C;
+    const int nv = o_be + C;
+
+    // this lane's parameter sums over the tiles it sees: fc1.weight[(l >> 5) + 2u][l & 31], u < 16; fc2.weight
+    // element l + 64u, u < 2; fc1.bias (lanes < 32) or fc2.bias (lanes 32..32+nc-1); gamma (lanes < 32) or beta
+    float g_w1[16], g_w2[2] = {0.f, 0.f}, g_b = 0.f, g_gb = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) g_w1[u] = 0.f;
+    float nll_sum = 0.f;                                 // lane 0: this block's rows, in order
+
+    for (; t < n_tiles; t += gridDim.x) {
+        if (t != (long long)blockIdx.x) {                // later tiles of a batch of more than 8 x 256 rows
+            row = t * kRows + r;
+            valid = row < dm.g;
+            kv = ld4(k + (valid ? row : dm.g - 1) * C + 4 * s);
+            label = labels[valid ? row : dm.g - 1];
+        }
+        // ---- forward ----
+        const float kk[4] = {kv.x, kv.y, kv.z, kv.w};
+        float y[4], xh[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y[e] = fmaf(kk[e], sc[e], shift[e]);
+            xh[e] = (kk[e] - mean[e]) * invstd[e];
+        }
+        float part[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j)
+            part[j] = fmaf(y[3], wf[j].w, fmaf(y[2], wf[j].z, fmaf(y[1], wf[j].y, y[0] * wf[j].x)));
+        float h[4];
+        reduce_scatter8(part, s, h);                     // hidden units 4s..4s+3 of row r
+        {
+            const float bb[4] = {b1v.x, b1v.y, b1v.z, b1v.w};
+            uint32_t wv[4] = {0, 0, 0, 0};
+            if (drop) {
+                const RwkPhilox4 rr = rwk_philox4x32_10((uint32_t)row, (uint32_t)s, kHeadCall, off_lo, seed_lo, key_hi);
+                wv[0] = rr.x; wv[1] = rr.y; wv[2] = rr.z; wv[3] = rr.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = h[e] + bb[e];
+                a = a > 0.f ? a : 0.f;
+                if (drop) a = wv[e] < keep_thr ? a * keep_scale : 0.f;
+                h[e] = a;
+            }
+        }
+        float o[NCM];
+#pragma unroll
+        for (int q = 0; q < NCM; ++q) {
+            float a = fmaf(h[3], w2v[q].w, fmaf(h[2], w2v[q].z, fmaf(h[1], w2v[q].y, h[0] * w2v[q].x)));
+            o[q] = rwk_group_sum(a, 8) + b2v[q];
+        }
+        // log-softmax, the cross-entropy of the stored log-probabilities and its gradient for d_loss = 1
+        // (head_train_kernel's expressions; every lane of the row computes them)
+        float dl[NCM];
+        {
+            float mx = o[0];
+#pragma unroll
+            for (int q = 1; q < NCM; ++q) if (q < nc) mx = fmaxf(mx, o[q]);
+            float se = 0.f;
+#pragma unroll
+            for (int q = 0; q < NCM; ++q) if (q < nc) se += expf(o[q] - mx);
+            const float lse = mx + logf(se);
+#pragma unroll
+            for (int q = 0; q < NCM; ++q) o[q] -= lse;
+            if (valid && s < nc) {
+                float mine = o[0];
+#pragma unroll
+                for (int q = 1; q < NCM; ++q) mine = s == q ? o[q] : mine;
+                out[row * nc + s] = mine;
+            }
+            float mx2 = o[0];
+#pragma unroll
+            for (int q = 1; q < NCM; ++q) if (q < nc) mx2 = fmaxf(mx2, o[q]);
+            float se2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < NCM; ++q) if (q < nc) se2 += expf(o[q] - mx2);
+            const float lse2 = mx2 + logf(se2);
+            long long cls = label;
+            cls = cls < 0 ? 0 : (cls >= nc ? nc - 1 : cls);  // the host side has checked the range (see head.py)
+            float o_cls = o[0];
+#pragma unroll
+            for (int q = 1; q < NCM; ++q) o_cls = cls == q ? o[q] : o_cls;
+            const float nll = valid ? lse2 - o_cls : 0.f;
+            // rows of the tile in order, on lane 0 (the value of lane 8 r' is row r')
+#pragma unroll
+            for (int rr = 0; rr < kRows; ++rr) nll_sum += __shfl(nll, 8 * rr, 64);
+            float go[NCM], sgo = 0.f;
+#pragma unroll
+            for (int q = 0; q < NCM; ++q) {
+                go[q] = q < nc ? inv_g * (expf(o[q] - lse2) - (q == cls ? 1.f : 0.f)) : 0.f;
+                sgo += go[q];
+            }
+#pragma unroll
+            for (int q = 0; q < NCM; ++q) dl[q] = (valid && q < nc) ? go[q] - expf(o[q]) * sgo : 0.f;
+        }
+        // ---- backward, per-tile part ----
+        float dp[4];
+        {
+            const float w2e[NCM][4] = {{w2v[0].x, w2v[0].y, w2v[0].z, w2v[0].w}, {w2v[1].x, w2v[1].y, w2v[1].z, w2v[1].w},
+                                       {w2v[2].x, w2v[2].y, w2v[2].z, w2v[2].w}, {w2v[3].x, w2v[3].y, w2v[3].z, w2v[3].w}};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = 0.f;
+#pragma unroll
+                for (int q = 0; q < NCM; ++q) a = fmaf(dl[q], w2e[q][e], a);
+                dp[e] = h[e] > 0.f ? a * keep_scale : 0.f;
+            }
+        }
+        float dyv[4];
+        {
+            float pd[C];
+#pragma unroll
+            for (int cg = 0; cg < C / 4; ++cg) {
+                pd[4 * cg + 0] = fmaf(dp[3], wb[3][cg].x, fmaf(dp[2], wb[2][cg].x, fmaf(dp[1], wb[1][cg].x, dp[0] * wb[0][cg].x)));
+                pd[4 * cg + 1] = fmaf(dp[3], wb[3][cg].y, fmaf(dp[2], wb[2][cg].y, fmaf(dp[1], wb[1][cg].y, dp[0] * wb[0][cg].y)));
+                pd[4 * cg + 2] = fmaf(dp[3], wb[3][cg].z, fmaf(dp[2], wb[2][cg].z, fmaf(dp[1], wb[1][cg].z, dp[0] * wb[0][cg].z)));
+                pd[4 * cg + 3] = fmaf(dp[3], wb[3][cg].w, fmaf(dp[2], wb[2][cg].w, fmaf(dp[1], wb[1][cg].w, dp[0] * wb[0][cg].w)));
+            }
+            reduce_scatter8(pd, s, dyv);                 // dY[r][4s..4s+3]
+        }
+        if (valid) *reinterpret_cast<float4 *>(dy + row * C + 4 * s) = make_float4(dyv[0], dyv[1], dyv[2], dyv[3]);
+        // ---- this tile's share of the parameter sums: the rows meet in LDS (rows past the batch are zero there) ----
+        __syncthreads();                                 // the previous tile's readers are done (one wavefront: a wait)
+        {
+            const float z = valid ? 1.f : 0.f;
+            *reinterpret_cast<float4 *>(&s_h[r][4 * s]) = make_float4(h[0] * z, h[1] * z, h[2] * z, h[3] * z);
+            *reinterpret_cast<float4 *>(&s_dp[r][4 * s]) = make_float4(dp[0] * z, dp[1] * z, dp[2] * z, dp[3] * z);
+            *reinterpret_cast<float4 *>(&s_dyt[r][4 * s]) = make_float4(dyv[0] * z, dyv[1] * z, dyv[2] * z, dyv[3] * z);
+            *reinterpret_cast<float4 *>(&s_xh[r][4 * s]) = make_float4(xh[0] * z, xh[1] * z, xh[2] * z, xh[3] * z);
+            if (s < NCM) {
+                float mine = dl[0];
+#pragma unroll
+                for (int q = 1; q < NCM; ++q) mine = s == q ? dl[q] : mine;
+                s_dl[r][s] = mine;
+            }
+        }
+        __syncthreads();
+        {
+            const int col = l & 31;
+            float yv[kRows], dyc[kRows], xhc[kRows];
+#pragma unroll
+            for (int rr = 0; rr < kRows; ++rr) {
+                xhc[rr] = s_xh[rr][col];
+                dyc[rr] = s_dyt[rr][col];
+            }
+#pragma unroll
+            for (int rr = 0; rr < kRows; ++rr) yv[rr] = fmaf(xhc[rr], ga_c, be_c);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int j = (l >> 5) + 2 * u;
+                float a = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < kRows; ++rr) a = fmaf(s_dp[rr][j], yv[rr], a);
+                g_w1[u] += a;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {                // fc2.weight[q][j], element l + 64u
+                const int e = l + 64 * u;
+                const int q = (e >> 5) < nc ? (e >> 5) : nc - 1, j = e & 31;
+                float a = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < kRows; ++rr) a = fmaf(s_dl[rr][q], s_h[rr][j], a);
+                g_w2[u] += a;
+            }
+            {                                            // fc1.bias[l] on lanes < 32, fc2.bias[l - 32] on the others
+                const int q = (l - 32) < nc ? (l & 31) : nc - 1;
+                float a = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < kRows; ++rr) a += l < 32 ? s_dp[rr][col] : s_dl[rr][q < NCM ? q : 0];
+                g_b += a;
+            }
+            {                                            // gamma[col] on lanes < 32, beta[col] on the others
+                float a = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < kRows; ++rr) a = l < 32 ? fmaf(dyc[rr], xhc[rr], a) : a + dyc[rr];
+                g_gb += a;
+            }
+        }
+    }
+    // ---- this block's partial row, in head_train_kernel's layout ----
+    float *dst = grad_partials + (size_t)blockIdx.x * nv;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (l + 64 * u < o_b2) dst[l + 64 * u] = g_w2[u];
+    if (l >= 32 && l - 32 < nc) dst[o_b2 + (l - 32)] = g_b;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) dst[o_w1 + l + 64 * u] = g_w1[u];
+    if (l < 32) {
+        dst[o_b1 + l] = g_b;
+        dst[o_ga + l] = g_gb;
+    } else {
+        dst[o_be + (l - 32)] = g_gb;
+    }
+    if (l == 0) loss_partials[blockIdx.x] = nll_sum;
 }
 
 // partials[b][e] added over b = lane8, lane8 + 8, ... in that order, eight loads in flight at a time
@@ -1118,7 +1556,7 @@ size_t bwd_lds(int c, int p, int nc) {
 size_t train_lds(int c, int p, int nc) {
     return sizeof(float) * ((size_t)p * (c + 1) + (size_t)nc * (p + 1) + p + nc + 6 * (size_t)c +
                             2 * (size_t)kRows * (c + 1) + 2 * (size_t)kRows * (p + 1) + 2 * (size_t)kRows * nc +
-                            head_nv(c, p, nc));
+                            head_nv(c, p, nc) + 1);
 }
 
 bool dims_ok(int64_t g, int64_t c, int64_t p, int64_t nc) {
@@ -1140,8 +1578,8 @@ int allow_lds(K kern, size_t lds) {
 extern "C" {
 
 #ifdef RWK_STAMP
-int rwk_debug_read_head_stamps(unsigned long long *host16) {
-    return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(rwk_head_stamp_buf), sizeof(unsigned long long) * 16);
+int rwk_debug_read_head_stamps(unsigned long long *host32) {
+    return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(rwk_head_stamp_buf), sizeof(unsigned long long) * 32);
 }
 #endif
 
@@ -1151,7 +1589,7 @@ int rwk_head_supported(int64_t g, int64_t c, int64_t p, int64_t nc) {
 
 int64_t rwk_head_n_blocks(int64_t g) { return g >= 1 ? head_blocks(g) : 0; }
 
-int64_t rwk_head_stats_size(int64_t g, int64_t c) { return g >= 1 ? (int64_t)head_blocks(g) * (1 + 2 * c) : 0; }
+int64_t rwk_head_stats_size(int64_t g, int64_t c) { return g >= 1 ? (int64_t)head_blocks(g) * stats_stride((int)c) : 0; }
 
 int64_t rwk_head_grad_size(int64_t c, int64_t p, int64_t nc) { return head_nv((int)c, (int)p, (int)nc); }
 
@@ -1399,6 +1837,18 @@ int rwk_head_train_forward(const float *k, int64_t g, int64_t c, int64_t p, int6
     const size_t lds = train_lds((int)c, (int)p, (int)nc);
     const int rc = allow_lds(head_train_kernel, lds);
     if (rc != RWK_OK) return rc;
+    // the reference's default widths with every vector operand 16-byte aligned: the one-wavefront-per-tile kernel
+    const auto aligned16 = [](const void *q) { return ((uintptr_t)q & 15u) == 0; };
+    if (c == kT32 && p == kT32 && nc <= kT32MaxNC && aligned16(k) && aligned16(bn_w) && aligned16(bn_b) &&
+        aligned16(running_mean) && aligned16(running_var) && aligned16(stats) && aligned16(w1) && aligned16(b1) &&
+        aligned16(w2) && aligned16(dy)) {
+        hipLaunchKernelGGL(head_train32_kernel, dim3(head_blocks(g)), dim3(kT32Threads), 0, stream, k, dm, bn_w, bn_b,
+                           running_mean, running_var, (long long *)num_batches_tracked, momentum, eps,
+                           (const float *)stats, n_stats, w1, b1, w2, b2, drop_p, (const unsigned long long *)rng_used,
+                           mean_out, invstd_out, out, (const long long *)labels, loss_partials, dy, partials, loss);
+        RWK_LAUNCH_CHECK();
+        return RWK_OK;
+    }
     hipLaunchKernelGGL(head_train_kernel, dim3(head_blocks(g)), dim3(kBlock), lds, stream, k, dm, bn_w, bn_b,
                        running_mean, running_var, (long long *)num_batches_tracked, momentum, eps,
                        (const float *)stats, n_stats, w1, b1, w2, b2, drop_p, (const unsigned long long *)rng_used,

@@ -18,9 +18,19 @@ for _ in range(5):
     tr.step_eager()
 torch.cuda.synchronize()
 lib = _lib.load()
-buf = (ctypes.c_uint64 * 16)()
+buf = (ctypes.c_uint64 * 32)()
 lib.rwk_debug_read_head_stamps.restype = ctypes.c_int
 print('rc', lib.rwk_debug_read_head_stamps(buf))
 a = list(buf)
 print('apply   : stats+params %d | s_y %d | fc1+dropout %d | fc2 %d | log-softmax %d' % tuple(a[0:5]))
 print('bwd_tile: loads+stores %d | d pre-act %d | dY %d | param grads %d | write partials %d' % tuple(a[8:13]))
+print('train   : params+stats %d | normalise %d | fc1+dropout %d | fc2 %d | log-softmax+loss %d | d pre-act %d | dY %d | param grads %d | stores %d'
+      % tuple(a[16:25]))
+for _ in range(20):
+    tr.step_eager()
+torch.cuda.synchronize()
+lib.rwk_debug_read_head_stamps(buf)
+a = list(buf)
+print('train   : params+stats %d | normalise %d | fc1+dropout %d | fc2 %d | log-softmax+loss %d | d pre-act %d | dY %d | param grads %d | stores %d'
+      % tuple(a[16:25]))
+print('train prologue: issue param loads %d | issue stats loads %d | params to LDS %d | merge %d | finish cols %d | barrier->%d' % tuple(a[25:30] + [a[16]]))

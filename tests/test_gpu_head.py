@@ -210,7 +210,9 @@ def test_head_with_loss_equals_head_then_cross_entropy(dev, g, c, p, nc):
     """fused_head_loss (the cross-entropy inside the head's launches) against fused_head followed by
     gnn_amd.losses.cross_entropy: same log-probabilities bit for bit, the same gradients (the loss gradient is formed
     by the same expressions, in place: equal bits expected, 1e-6 allowed), the loss value to 1e-6 (its rows are added
-    in another order), and against the float64 torch reference at the tolerances of the separate path."""
+    in another order), and against the float64 torch reference at the tolerances of the separate path.  At 32 x 32
+    with at most four classes the training step runs the one-wavefront-per-tile kernel, whose inner products are
+    added in another order: log-probabilities to 2e-6 and gradients to 2e-5 of the separate path there."""
     from gnn_amd.head import fused_head, fused_head_loss
     from gnn_amd.losses import cross_entropy
     m, m64, k, y = make_case(g, c, p, nc, True)
@@ -231,13 +233,18 @@ def test_head_with_loss_equals_head_then_cross_entropy(dev, g, c, p, nc):
     assert not out_b.requires_grad
     loss_b.backward()
     torch.cuda.synchronize()
-    assert torch.equal(out_a.detach(), out_b)
+    one_wave = c == 32 and p == 32 and nc <= 4
+    if one_wave:
+        assert rel(out_b, out_a.detach()) < 2e-6
+    else:
+        assert torch.equal(out_a.detach(), out_b)
+    same = 2e-5 if one_wave else 1e-6
     assert abs(float(loss_a) - float(loss_b)) < 1e-6 * abs(float(loss_a))
     assert abs(float(loss_b) - float(loss_ref)) < TOL * abs(float(loss_ref))
-    assert rel(kb.grad, ka.grad) < 1e-6
+    assert rel(kb.grad, ka.grad) < same
     assert rel(kb.grad, k64.grad) < 5e-5
     for (name, pa), (_, pb), (_, ref) in zip(ma.named_parameters(), mb.named_parameters(), m64.named_parameters()):
-        assert rel(pb.grad, pa.grad) < 1e-6, name
+        assert rel(pb.grad, pa.grad) < same, name
         assert rel(pb.grad, ref.grad) < 1e-4, name
     assert torch.equal(ma.bn.running_mean, mb.bn.running_mean)
     assert torch.equal(ma.bn.running_var, mb.bn.running_var)
@@ -283,8 +290,9 @@ def test_model_forward_with_loss(dev):
     out_b, loss_b = mb.forward_with_loss(adj, feats, gi, y)
     loss_b.backward()
     torch.cuda.synchronize()
-    assert torch.equal(out_a.detach(), out_b)
-    assert abs(float(loss_a) - float(loss_b)) < 1e-6 * abs(float(loss_a))
+    # 32 x 32 head: the training step's one-wavefront kernel adds the inner products in another order
+    assert rel(out_b, out_a.detach()) < 2e-6
+    assert abs(float(loss_a) - float(loss_b)) < 2e-6 * abs(float(loss_a))
     for (name, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
         assert rel(pb.grad, pa.grad) < 2e-5, name
 
