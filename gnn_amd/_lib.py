@@ -79,8 +79,8 @@ SIGNATURES = {
                                           _P]),
     "rwk_hidden_backward_reduce": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _I64, _I64, _P,
                                            _P]),
-    "rwk_fused_reduce_stats_rows": (_I64, [_I64]),
-    "rwk_fused_reduce_stats_blocks": (_I64, [_I64]),
+    "rwk_fused_reduce_stats_rows": (_I64, [_I64, _I64]),
+    "rwk_fused_reduce_stats_blocks": (_I64, [_I64, _I64]),
     "rwk_fused_reduce_stats": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, c_float, c_int, _P, _P, _P, _P, _P]),
     "rwk_head_apply_loss": (c_int, [_P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, c_float, c_float, _P, _I64, _P,
                                     _P, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -57,7 +57,7 @@ def _plan(lib, st: GraphStructure, d: int, n_hidden: int, s: int, steps: int):
             "dz_rows32": int(lib.rwk_reduce_rows_level1(n_part)) if n_part > 32 else n_part,
             "ws": int(lib.rwk_fused_backward_workspace(n, d, n_hidden, s, steps)),
             "stats_size": int(lib.rwk_head_stats_size(g, steps * n_hidden)),
-            "stats_blocks": int(lib.rwk_fused_reduce_stats_blocks(g)),
+            "stats_blocks": int(lib.rwk_fused_reduce_stats_blocks(g, steps * n_hidden)),
             "spb_blocks": int(lib.rwk_spmm_project_backward_blocks(n)),
         }
         st.plans[key] = plan

@@ -289,13 +289,13 @@ int rwk_head_backward_loss(const float *k, int64_t g, int64_t c, int64_t p, int6
                            float *loss, rwk_stream_t stream);
 
 /* rwk_fused_reduce (model.py:60-64,67) and the batch statistics of the K it writes (first half of model.py:68) in one
- * launch: stats receives rwk_fused_reduce_stats_blocks(g) block partials {count, mean[C], M2[C]}, C = h * max_step
- * <= 256, each over rwk_fused_reduce_stats_rows(g) consecutive rows (room for them: rwk_head_stats_size(g, C)
+ * launch: stats receives rwk_fused_reduce_stats_blocks(g, C) block partials {count, 3 unused, mean[C], M2[C]},
+ * C = h * max_step <= 256, each over rwk_fused_reduce_stats_rows(g, C) consecutive rows (room for them: rwk_head_stats_size(g, C)
  * floats); rng_state / rng_used not NULL: the head's dropout generator state is drawn and advanced, as the
  * statistics launch of rwk_head_forward does.  rwk_head_apply_loss is rwk_head_forward_loss in training mode without
  * its statistics launch, on such partials. */
-int64_t rwk_fused_reduce_stats_rows(int64_t g);
-int64_t rwk_fused_reduce_stats_blocks(int64_t g);
+int64_t rwk_fused_reduce_stats_rows(int64_t g, int64_t c);
+int64_t rwk_fused_reduce_stats_blocks(int64_t g, int64_t c);
 int rwk_fused_reduce_stats(const float *k_partials, const int32_t *seg_ptr, const float *counts_f32, int64_t n_graphs,
                            int64_t h, int64_t max_step, int64_t stream_len, float drop_p, int normalize, float *k,
                            float *stats, uint64_t *rng_state, uint64_t *rng_used, rwk_stream_t stream);

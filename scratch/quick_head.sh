@@ -5,8 +5,8 @@ out=gpurun_out/quick_head; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 timeout -k 10 300 python3 -u -m pytest tests/test_gpu_head.py tests/test_gpu_aux.py -x -q -m gpu --timeout 120 --timeout-method thread > $out/tests.log 2>&1 || { tail -30 $out/tests.log; exit 1; }
 tail -2 $out/tests.log
-true
-true
+timeout -k 10 200 python3 -u scratch/stamp_head.py > $out/stamp.log 2>&1 || { tail -20 $out/stamp.log; exit 1; }; tail -1 $out/stamp.log
+timeout -k 10 200 python3 -u scratch/stamp_head.py > $out/stamp.log 2>&1 || { tail -20 $out/stamp.log; exit 1; }; tail -1 $out/stamp.log
 timeout -k 10 300 python3 -u bench.py --no-cpu-baseline > $out/bench.json 2> $out/bench.err || { tail -20 $out/bench.err; exit 1; }
 python3 -c "
 import json; d=json.load(open('$out/bench.json')); print('ms_per_step', d['ms_per_step'], 'value', d['value'])"

@@ -34,3 +34,4 @@ a = list(buf)
 print('train   : params+stats %d | normalise %d | fc1+dropout %d | fc2 %d | log-softmax+loss %d | d pre-act %d | dY %d | param grads %d | stores %d'
       % tuple(a[16:25]))
 print('train prologue: issue param loads %d | issue stats loads %d | params to LDS %d | merge %d | finish cols %d | barrier->%d' % tuple(a[25:30] + [a[16]]))
+print('train32: issue loads %d | stats loads back + block sums %d | merge %d | setup %d | BN + fc1 products %d | reduce-scatter, relu, dropout %d | fc2 %d | softmax, loss, dlogits %d | d pre-act, dY %d | dY store, LDS staging %d | parameter sums %d | stores %d' % tuple(a[16:28]))
