@@ -1460,6 +1460,36 @@ head_train32_kernel(const float *__restrict__ k, HeadDims dm, const float *__res
     HEAD_STAMP_AT(27);
 }
 
+// The first 128 block partials of one element, fetched ahead of their use: lane8 holds blocks lane8, lane8 + 8, ...
+// sum() adds them in sum_partials8's order (and goes on with any further blocks as it does).
+struct FinPartials {
+    float v[16];
+    __device__ inline void load(const float *__restrict__ partials, int n_partials, int nv, int e, int lane8) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int b = lane8 + 8 * u;
+            v[u] = partials[(size_t)(b < n_partials ? b : n_partials - 1) * nv + e];
+        }
+    }
+    __device__ inline float sum(const float *__restrict__ partials, int n_partials, int nv, int e, int lane8) const {
+        float acc = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += lane8 + 8 * u < n_partials ? v[u] : 0.f;
+        for (int b0 = lane8 + 128; b0 < n_partials; b0 += 64) {
+            float w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + 8 * u;
+                w[u] = partials[(size_t)(b < n_partials ? b : n_partials - 1) * nv + e];
+                if (b >= n_partials) w[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += w[u];
+        }
+        return acc;
+    }
+};
+
 // partials[b][e] added over b = lane8, lane8 + 8, ... in that order, eight loads in flight at a time
 __device__ inline float sum_partials8(const float *__restrict__ partials, int n_partials, int nv, int e, int lane8) {
     float acc = 0.f;
@@ -1493,65 +1523,101 @@ head_bwd_finish_kernel(const float *__restrict__ k, HeadDims dm, const float *__
     const int o_ga = nc * p + nc + p * c + p;
     // d_loss not null: dy and the partials were computed for d(loss) = 1 (head_train_kernel) and take the factor here
     const float dl = d_loss != nullptr ? d_loss[0] : 1.f;
-    if (loss_out != nullptr && blockIdx.x == gridDim.x - 1 && tid < 64) {
-        // mean loss from the forward launch's per-block sums: lane l adds blocks l, l + 64, ... in order (at most
-        // kMaxBlocks = 256: four loads in flight), then a butterfly whose operand pairs are fixed
-        float v[4];
+    // mean loss from the forward launch's per-block sums, by the first wavefront of the last block: lane l adds blocks
+    // l, l + 64, ... in order (at most kMaxBlocks = 256), then a butterfly whose operand pairs are fixed.  Requested
+    // here with everything else, finished at the end of the kernel.
+    const bool loss_wave = loss_out != nullptr && blockIdx.x == gridDim.x - 1 && tid < 64;
+    float loss_v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (loss_wave) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int b = tid + 64 * u;
-            v[u] = loss_partials[b < n_partials ? b : n_partials - 1];
-            if (b >= n_partials) v[u] = 0.f;
+            loss_v[u] = loss_partials[b < n_partials ? b : n_partials - 1];
         }
-        float acc = ((v[0] + v[1]) + v[2]) + v[3];
+    }
+    auto finish_loss = [&]() {
+        if (!loss_wave) return;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (tid + 64 * u >= n_partials) loss_v[u] = 0.f;
+        float acc = ((loss_v[0] + loss_v[1]) + loss_v[2]) + loss_v[3];
         for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
         if (tid == 0) loss_out[0] = acc / (float)dm.g;
-    }
-    // this block's slice of the parameter gradients: eight lanes share the block partials of one element
-    // (independent loads in flight) and are then added in a fixed butterfly order
+    };
+    // Everything below depends on loads that do not depend on each other: the block partials of this block's slice of
+    // the parameter gradients, those of the gamma / beta columns, and the first tile's rows.  They are all requested
+    // before the first of them is waited for (one round trip instead of eight); what does not fit the prefetch
+    // (more than 128 partials, more than 32 elements or 64 columns per block, later tiles) is loaded where it is used.
     const int lane8 = tid & 7, grp = tid >> 3;
     const int per = (nv + gridDim.x - 1) / gridDim.x;
     const int e_lo = blockIdx.x * per, e_hi = e_lo + per < nv ? e_lo + per : nv;
-    for (int e0 = e_lo; e0 < e_hi; e0 += kBlock / 8) {      // uniform trip count: the shuffles need all lanes
+    const int n_cols2 = d_k != nullptr ? 2 * c : 0;
+    const long long n_tiles = (dm.g + kRows - 1) / kRows;
+    FinPartials pre_e, pre_c[2];
+    if (e_lo < e_hi) pre_e.load(partials, n_partials, nv, e_lo + grp < e_hi ? e_lo + grp : e_hi - 1, lane8);
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+        if (it * (kBlock / 8) < n_cols2) {
+            const int q = it * (kBlock / 8) + grp;
+            pre_c[it].load(partials, n_partials, nv, o_ga + (q < 2 * c ? q : 2 * c - 1), lane8);
+        }
+    float t_dy = 0.f, t_k = 0.f, t_sc = 0.f, t_mu = 0.f, t_is = 0.f;
+    const FastDiv by_c(c);
+    if (d_k != nullptr && (long long)blockIdx.x < n_tiles) {
+        const long long r0 = (long long)blockIdx.x * kRows;
+        const int nr = (int)(dm.g - r0 < kRows ? dm.g - r0 : kRows);
+        const int i = tid < nr * c ? tid : 0;
+        const int col = by_c.mod(i);
+        t_dy = dy[r0 * c + i];
+        t_k = k[r0 * c + i];
+        t_is = invstd[col];
+        t_sc = bn_w[col] * t_is;
+        t_mu = mean[col];
+    }
+    for (int e0 = e_lo; e0 < e_hi; e0 += kBlock / 8) {      // uniform trip count: the butterfly needs all lanes
         const int e = e0 + grp;
         const int ec = e < e_hi ? e : e_hi - 1;
-        float acc = sum_partials8(partials, n_partials, nv, ec, lane8);
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        acc += __shfl_xor(acc, 4, 64);
+        float acc = e0 == e_lo ? pre_e.sum(partials, n_partials, nv, ec, lane8)
+                               : sum_partials8(partials, n_partials, nv, ec, lane8);
+        acc = rwk_group_sum(acc, 8);
         if (lane8 == 0 && e < e_hi) grads[e] = acc * dl;
     }
-    if (d_k == nullptr) return;
+    if (d_k == nullptr) {
+        finish_loss();
+        return;
+    }
     for (int c0 = 0; c0 < 2 * c; c0 += kBlock / 8) {
         const int q = c0 + grp;                              // q < c: dgamma column, else dbeta column
         const int qc = q < 2 * c ? q : 2 * c - 1;
-        float acc = sum_partials8(partials, n_partials, nv, o_ga + qc, lane8);
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        acc += __shfl_xor(acc, 4, 64);
+        float acc;
+        if (c0 == 0) acc = pre_c[0].sum(partials, n_partials, nv, o_ga + qc, lane8);
+        else if (c0 == kBlock / 8) acc = pre_c[1].sum(partials, n_partials, nv, o_ga + qc, lane8);
+        else acc = sum_partials8(partials, n_partials, nv, o_ga + qc, lane8);
+        acc = rwk_group_sum(acc, 8);
         if (lane8 == 0 && q < 2 * c) {
             if (q < c) s_dga[q] = acc * dl; else s_dbe[q - c] = acc * dl;
         }
     }
     __syncthreads();
     const float inv_g = 1.f / (float)dm.g;
-    const FastDiv by_c(c);
-    const long long n_tiles = (dm.g + kRows - 1) / kRows;
     for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const long long r0 = t * kRows;
         const int nr = (int)(dm.g - r0 < kRows ? dm.g - r0 : kRows);
         for (int i = tid; i < nr * c; i += kBlock) {
             const int col = by_c.mod(i);
             const long long at = r0 * c + i;
-            const float sc = bn_w[col] * invstd[col];
-            float v = dy[at] * dl;
+            const bool pre = t == (long long)blockIdx.x && i == tid;
+            const float is = pre ? t_is : invstd[col];
+            const float sc = pre ? t_sc : bn_w[col] * is;
+            float v = (pre ? t_dy : dy[at]) * dl;
             if (training) {
-                const float xh = (k[at] - mean[col]) * invstd[col];
+                const float xh = ((pre ? t_k : k[at]) - (pre ? t_mu : mean[col])) * is;
                 v = v - s_dbe[col] * inv_g - xh * s_dga[col] * inv_g;
             }
             d_k[at] = v * sc;
         }
     }
+    finish_loss();
 }
 
 // ---------------------------------------------------------------------------------------------------
