@@ -79,6 +79,10 @@ SIGNATURES = {
                                           _P]),
     "rwk_hidden_backward_reduce": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _I64, _I64, _P,
                                            _P]),
+    "rwk_step_tail_n_counters": (_I64, [_I64, _I64, _I64]),
+    "rwk_hidden_backward_reduce_adam": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _I64, _I64,
+                                                _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _I64, _P,
+                                                c_float, c_float, c_float, c_float, _P, _P]),
     "rwk_fused_reduce_stats_rows": (_I64, [_I64, _I64]),
     "rwk_fused_reduce_stats_blocks": (_I64, [_I64, _I64]),
     "rwk_fused_reduce_stats": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, c_float, c_int, _P, _P, _P, _P, _P]),

@@ -78,12 +78,20 @@ __device__ inline void hidden_forward_body(int h, float *lds, const float *__res
     }
 }
 
+// What else happens to a finished gradient element in the thread that holds it (nothing by default; the training
+// step's last launch applies the optimiser's update there, see rwk_step.hip).
+struct NoGradTail {
+    __device__ inline void features_hidden(long long /*index*/, float /*g*/) const {}
+    __device__ inline void adj_hidden(long long /*index*/, float /*g*/) const {}
+};
+
 // workgroup `h` of kHiddenBlock threads; lds: 2*s*s + (1 + n_slices) * max_step*s*d floats
+template <typename TAIL = NoGradTail>
 __device__ inline void hidden_backward_body(int h, float *lds, const float *__restrict__ adj_hidden,
                                             const float *__restrict__ ah_in, const float *__restrict__ z,
                                             const float *__restrict__ dz_partials, int n_partials, int n_hidden,
                                             int s, int d, int max_step, float *__restrict__ d_adj_hidden,
-                                            float *__restrict__ d_feat, int n_slices) {
+                                            float *__restrict__ d_feat, int n_slices, const TAIL &tail = TAIL()) {
     constexpr int kBlock = kHiddenBlock;
     const int sd = s * d;
     const int v_total = max_step * sd;           // gradient values owned by this hidden graph
@@ -148,13 +156,18 @@ __device__ inline void hidden_backward_body(int h, float *lds, const float *__re
     }
 
     // 3. outputs
-    for (int i = tid; i < sd; i += kBlock) d_feat[(size_t)h * sd + i] = dz[i];
+    for (int i = tid; i < sd; i += kBlock) {
+        d_feat[(size_t)h * sd + i] = dz[i];
+        tail.features_hidden((long long)h * sd + i, dz[i]);
+    }
     const int n_pairs = s * (s - 1) / 2;
     for (int k = tid; k < n_pairs; k += kBlock) {
         int r, c;
         triu_pair(k, s, &r, &c);
         const float a = adj_hidden[(size_t)h * n_pairs + k];
-        d_adj_hidden[(size_t)h * n_pairs + k] = a > 0.f ? dah[r * s + c] + dah[c * s + r] : 0.f;
+        const float g = a > 0.f ? dah[r * s + c] + dah[c * s + r] : 0.f;
+        d_adj_hidden[(size_t)h * n_pairs + k] = g;
+        tail.adj_hidden((long long)h * n_pairs + k, g);
     }
 }
 

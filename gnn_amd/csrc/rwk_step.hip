@@ -15,8 +15,13 @@ constexpr size_t kLdsLimit = 160 * 1024;
 // Column sums of a (p, v) matrix with v <= 64 by one workgroup of 256 threads: 256 / vp lanes per column (vp = v
 // rounded up to a power of two), lane l adds rows l, l + lanes, ... in order (four loads in flight), then the lanes of
 // a column are added in a fixed halving tree.  lds: 256 floats.
+struct NoSumTail {
+    __device__ inline void column(int /*col*/, float /*sum*/) const {}
+};
+
+template <typename TAIL = NoSumTail>
 __device__ inline void reduce_rows_small256_body(float *red, const float *__restrict__ in, int p, int v, int vp,
-                                                 float *__restrict__ out) {
+                                                 float *__restrict__ out, const TAIL &tail = TAIL()) {
     const int tid = threadIdx.x;
     const int colv = tid % vp, lane = tid / vp, lanes = kBlock / vp;
     const int cc = colv < v ? colv : v - 1;
@@ -38,7 +43,10 @@ __device__ inline void reduce_rows_small256_body(float *red, const float *__rest
         if (lane < off) red[tid] += red[tid + off * vp];
         __syncthreads();
     }
-    if (lane == 0 && colv < v) out[colv] = red[colv];
+    if (lane == 0 && colv < v) {
+        out[colv] = red[colv];
+        tail.column(colv, red[colv]);
+    }
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -53,6 +61,98 @@ hidden_backward_reduce_kernel(const float *__restrict__ adj_hidden, const float 
                              d_adj_hidden, d_feat_hidden, n_slices);
     else
         reduce_rows_small256_body(lds, red_in, red_p, red_v, red_vp, red_out);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same launch with the optimiser's update inside: the last launch of a single-process training step.
+// Adam (torch.optim.Adam's arithmetic, rwgnn2/main.py:79,87; the update of rwk_optim.hip's adam_step_kernel) is
+// element-wise, so the thread that finishes a gradient element applies it at once: hidden graph h's workgroup
+// updates its own rows of adj_hidden and features_hidden, the column-sum workgroup the input projection's weight
+// and bias, and further workgroups the remaining parameters (the head's), whose gradients an earlier launch left
+// in memory.  One launch less per step.  Every workgroup keeps its own step counter, as the stand-alone kernels do.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kTailChunks = 16;
+struct AdamTailArgs {
+    float *param, *exp_avg, *exp_avg_sq, *grad_out;      // flat buffers; grad_out may be null
+    const float *lr;
+    float beta1, beta2, eps, weight_decay;
+    long long *counters;
+    long long off_adj, off_feat, off_red;                // flat index of adj_hidden[0], features_hidden[0], column 0
+    long long rest_off, n;                               // the chunked remainder covers [rest_off, n)
+    const float *src[kTailChunks];
+    long long off[kTailChunks];                          // flat index each chunk starts at; unused: LLONG_MAX
+};
+
+__device__ inline double pow_int(double b, long long t) {
+    double r = 1.0;
+    while (t > 0) {
+        if (t & 1) r *= b;
+        b *= b;
+        t >>= 1;
+    }
+    return r;
+}
+
+__device__ inline void adam_element(const AdamTailArgs &a, const float *corr, long long i, float g) {
+    if (a.grad_out != nullptr) a.grad_out[i] = g;
+    const float p = a.param[i];
+    if (a.weight_decay != 0.f) g = fmaf(a.weight_decay, p, g);
+    const float m = fmaf(a.beta1, a.exp_avg[i], (1.f - a.beta1) * g);
+    const float v = fmaf(a.beta2, a.exp_avg_sq[i], (1.f - a.beta2) * g * g);
+    a.exp_avg[i] = m;
+    a.exp_avg_sq[i] = v;
+    const float denom = sqrtf(v) / corr[1] + a.eps;
+    a.param[i] = p - (a.lr[0] / corr[0]) * (m / denom);
+}
+
+struct HiddenAdamTail {
+    const AdamTailArgs &a;
+    const float *corr;
+    __device__ inline void features_hidden(long long index, float g) const { adam_element(a, corr, a.off_feat + index, g); }
+    __device__ inline void adj_hidden(long long index, float g) const { adam_element(a, corr, a.off_adj + index, g); }
+};
+struct SumAdamTail {
+    const AdamTailArgs &a;
+    const float *corr;
+    __device__ inline void column(int col, float sum) const { adam_element(a, corr, a.off_red + col, sum); }
+};
+
+__global__ void __launch_bounds__(kBlock)
+hidden_backward_reduce_adam_kernel(const float *__restrict__ adj_hidden, const float *__restrict__ ah_in,
+                                   const float *__restrict__ z, const float *__restrict__ dz_partials, int n_partials,
+                                   int n_hidden, int s, int d, int max_step, float *__restrict__ d_adj_hidden,
+                                   float *__restrict__ d_feat_hidden, int n_slices, const float *__restrict__ red_in,
+                                   int red_p, int red_v, int red_vp, float *__restrict__ red_out, AdamTailArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float corr[2];
+    if (threadIdx.x == 0) {
+        const long long t = a.counters[blockIdx.x] + 1;
+        a.counters[blockIdx.x] = t;
+        corr[0] = (float)(1.0 - pow_int((double)a.beta1, t));
+        corr[1] = (float)sqrt(1.0 - pow_int((double)a.beta2, t));
+    }
+    const int b = blockIdx.x;
+    if (b < n_hidden) {
+        // the body's own barriers stand between the write of corr and its first use
+        hidden_backward_body(b, lds, adj_hidden, ah_in, z, dz_partials, n_partials, n_hidden, s, d, max_step,
+                             d_adj_hidden, d_feat_hidden, n_slices, HiddenAdamTail{a, corr});
+    } else if (b == n_hidden) {
+        reduce_rows_small256_body(lds, red_in, red_p, red_v, red_vp, red_out, SumAdamTail{a, corr});
+    } else {
+        const long long i = a.rest_off + (long long)(b - n_hidden - 1) * kBlock + threadIdx.x;
+        const long long ic = i < a.n ? i : a.n - 1;
+        const float *src = a.src[0];
+        long long base = a.off[0];
+#pragma unroll
+        for (int k = 1; k < kTailChunks; ++k) {           // compare-select chain: a dynamic index would go to scratch
+            const bool ge = ic >= a.off[k];
+            src = ge ? a.src[k] : src;
+            base = ge ? a.off[k] : base;
+        }
+        const float g = src ? src[ic - base] : 0.f;
+        __syncthreads();
+        if (i < a.n) adam_element(a, corr, i, g);
+    }
 }
 
 template <typename K>
@@ -95,6 +195,82 @@ int rwk_hidden_backward_reduce(const float *adj_hidden, const float *ah, const f
                        adj_hidden, ah, z, dz_partials, (int)n_partials, (int)h, (int)s, (int)d, (int)max_step,
                        d_adj_hidden, d_features_hidden, (int)n_slices, red_in, (int)red_p, (int)red_v,
                        project_pow2_ceil((int)red_v), red_out);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
+/* rwk_hidden_backward_reduce with the Adam update of every parameter inside (see hidden_backward_reduce_adam_kernel).
+ * The flat buffers hold n parameters: adj_hidden at off_adj, features_hidden at off_feat, the red_v column sums
+ * (fc.weight | fc.bias) at off_red, and n_rest further tensors back to back from rest_off to n whose gradients are
+ * rest_srcs[k] (rest_sizes[k] floats each, NULL: zeros).  step_counters: rwk_step_tail_n_counters() int64, all at the
+ * same step count.  grad_out (may be NULL) receives the flat gradient. */
+int64_t rwk_step_tail_n_counters(int64_t h, int64_t n, int64_t rest_off) {
+    if (h <= 0 || n <= 0 || rest_off < 0 || rest_off > n) return 0;
+    return h + 1 + rwk_ceil_div(n - rest_off, kBlock);
+}
+
+int rwk_hidden_backward_reduce_adam(const float *adj_hidden, const float *ah, const float *z, const float *dz_partials,
+                                    int64_t n_partials, int64_t h, int64_t s, int64_t d, int64_t max_step,
+                                    float *d_adj_hidden, float *d_features_hidden, const float *red_in, int64_t red_p,
+                                    int64_t red_v, float *red_out, float *param, float *exp_avg, float *exp_avg_sq,
+                                    float *grad_out, int64_t n, int64_t off_adj, int64_t off_feat, int64_t off_red,
+                                    const float *const *rest_srcs, const int64_t *rest_sizes, int64_t n_rest,
+                                    int64_t rest_off, const float *lr, float beta1, float beta2, float eps,
+                                    float weight_decay, int64_t *step_counters, rwk_stream_t stream_) {
+    RWK_REQUIRE_PTR(adj_hidden);
+    RWK_REQUIRE_PTR(ah);
+    RWK_REQUIRE_PTR(z);
+    RWK_REQUIRE_PTR(dz_partials);
+    RWK_REQUIRE_PTR(d_adj_hidden);
+    RWK_REQUIRE_PTR(d_features_hidden);
+    RWK_REQUIRE_PTR(red_in);
+    RWK_REQUIRE_PTR(red_out);
+    RWK_REQUIRE_PTR(param);
+    RWK_REQUIRE_PTR(exp_avg);
+    RWK_REQUIRE_PTR(exp_avg_sq);
+    RWK_REQUIRE_PTR(lr);
+    RWK_REQUIRE_PTR(step_counters);
+    if (h <= 0 || s <= 1 || d <= 0 || max_step <= 1 || n_partials <= 0 || h > 65535) return RWK_E_SIZE;
+    if (red_p <= 0 || red_p > (1 << 20) || red_v <= 0) return RWK_E_SIZE;
+    if (red_v > 64) return RWK_E_UNSUPPORTED;
+    if (n_rest < 0 || n_rest > kTailChunks) return RWK_E_UNSUPPORTED;
+    if (n_rest > 0) {
+        RWK_REQUIRE_PTR(rest_srcs);
+        RWK_REQUIRE_PTR(rest_sizes);
+    }
+    const int64_t n_adj = h * (s * (s - 1) / 2), n_feat = h * s * d;
+    if (n <= 0 || off_adj < 0 || off_feat < 0 || off_red < 0 || rest_off < 0 || rest_off > n ||
+        off_adj + n_adj > rest_off || off_feat + n_feat > rest_off || off_red + red_v > rest_off)
+        return RWK_E_SIZE;
+    // the three in-kernel ranges must tile [0, rest_off) exactly: no parameter left out, none updated twice
+    if (n_adj + n_feat + red_v != rest_off) return RWK_E_SIZE;
+    if ((off_adj < off_feat + n_feat && off_feat < off_adj + n_adj) || (off_adj < off_red + red_v && off_red < off_adj + n_adj) ||
+        (off_feat < off_red + red_v && off_red < off_feat + n_feat))
+        return RWK_E_SIZE;
+    AdamTailArgs a;
+    a.param = param; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.grad_out = grad_out; a.lr = lr;
+    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
+    a.counters = (long long *)step_counters;
+    a.off_adj = off_adj; a.off_feat = off_feat; a.off_red = off_red; a.rest_off = rest_off; a.n = n;
+    long long off = rest_off;
+    for (int k = 0; k < kTailChunks; ++k) {
+        const bool used = k < n_rest;
+        if (used && rest_sizes[k] < 0) return RWK_E_SIZE;
+        a.src[k] = used ? rest_srcs[k] : nullptr;
+        a.off[k] = used ? off : 0x7FFFFFFFFFFFFFFFll;
+        if (used) off += rest_sizes[k];
+    }
+    if (off != n) return RWK_E_SIZE;
+    const int64_t n_slices = hidden_backward_slices(max_step * s * d, n_partials);
+    size_t lds = hidden_backward_lds(s, d, max_step, n_slices);
+    if (lds < kBlock * sizeof(float)) lds = kBlock * sizeof(float);
+    const int rc = allow_lds(hidden_backward_reduce_adam_kernel, lds);
+    if (rc != RWK_OK) return rc;
+    const unsigned grid = (unsigned)rwk_step_tail_n_counters(h, n, rest_off);
+    hipLaunchKernelGGL(hidden_backward_reduce_adam_kernel, dim3(grid), dim3(kBlock), lds, (hipStream_t)stream_,
+                       adj_hidden, ah, z, dz_partials, (int)n_partials, (int)h, (int)s, (int)d, (int)max_step,
+                       d_adj_hidden, d_features_hidden, (int)n_slices, red_in, (int)red_p, (int)red_v,
+                       project_pow2_ceil((int)red_v), red_out, a);
     RWK_LAUNCH_CHECK();
     return RWK_OK;
 }

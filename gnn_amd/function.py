@@ -155,6 +155,7 @@ class _RWKernelLayer(torch.autograd.Function):
         ctx.st = st
         ctx.cfg = (steps, bool(normalize), drop, projected)
         ctx.fuse_step = fuse_step
+        ctx.handoff = handoff
         ctx.save_for_backward(xs, z, ah, adj_hidden_c, rng_used, inp_c if projected else None, w_c)
         return k
 
@@ -216,10 +217,21 @@ class _RWKernelLayer(torch.autograd.Function):
                     partials.data_ptr(), _lib.ptr(d_inp), _lib.ptr(red_in), red_in.shape[0] if job else 0,
                     red_in.shape[1] if job else 0, _lib.ptr(red_out), stream), "rwk_spmm_project_backward")
                 wb = torch.empty(d * f + d, dtype=torch.float32, device=dev)
-                _lib.check(lib.rwk_hidden_backward_reduce(
-                    _lib.ptr(adj_hidden_c), ah.data_ptr(), z.data_ptr(), dz.data_ptr(), dz_rows, n_hidden, s, d, steps,
-                    _lib.ptr(d_adj), d_feat.data_ptr(), partials.data_ptr(), blocks, d * f + d, wb.data_ptr(), stream),
-                    "rwk_hidden_backward_reduce")
+                tail = ctx.handoff.get("tail") if ctx.handoff is not None else None
+                head = ctx.handoff.pop("head_grads", None) if tail is not None else None
+                if tail is not None and head is not None and s > 1 and not ctx.needs_input_grad[0]:
+                    # single-process training step: the optimiser's update rides in this launch (optim.StepTail)
+                    head_grads, hc, hp, hnc = head
+                    tail.launch(lib, stream, tail.head_sources(head_grads, hc, hp, hnc), _lib.ptr(adj_hidden_c),
+                                ah.data_ptr(), z.data_ptr(), dz.data_ptr(), dz_rows, n_hidden, s, d, steps,
+                                _lib.ptr(d_adj), d_feat.data_ptr(), partials.data_ptr(), blocks, d * f + d,
+                                wb.data_ptr())
+                    ctx.handoff["keep"] = head_grads          # the launch reads it asynchronously
+                else:
+                    _lib.check(lib.rwk_hidden_backward_reduce(
+                        _lib.ptr(adj_hidden_c), ah.data_ptr(), z.data_ptr(), dz.data_ptr(), dz_rows, n_hidden, s, d,
+                        steps, _lib.ptr(d_adj), d_feat.data_ptr(), partials.data_ptr(), blocks, d * f + d,
+                        wb.data_ptr(), stream), "rwk_hidden_backward_reduce")
                 d_w = wb[:d * f].view(d, f)
                 d_b = wb[d * f:]
                 return d_inp, d_w, d_b, d_adj, d_feat, None, None, None, None, None, None

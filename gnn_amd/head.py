@@ -208,6 +208,7 @@ class _FusedHeadLoss(torch.autograd.Function):
                 ctx.cfg = (training, drop, True)
                 ctx.save_for_backward(kc, bn_wc, mean, invstd, dy, partials, loss_partials, loss)
                 ctx.sizes = (p, nc)
+                ctx.handoff = handoff
                 ctx.mark_non_differentiable(out)
                 return out, loss
             h1d = torch.empty((g, p), dtype=torch.float32, device=dev) if needs_grad else None
@@ -241,6 +242,9 @@ class _FusedHeadLoss(torch.autograd.Function):
                     kc.data_ptr(), g, c, p, nc, bn_wc.data_ptr(), mean.data_ptr(), invstd.data_ptr(), dy.data_ptr(),
                     partials.data_ptr(), d_loss.data_ptr(), loss_partials.data_ptr(), loss.data_ptr(),
                     grads.data_ptr(), _lib.ptr(d_k), stream), "rwk_head_train_backward")
+            if ctx.handoff is not None and ctx.handoff.get("tail") is not None:
+                # the random-walk layer's backward (which runs next) updates the head's parameters from this buffer
+                ctx.handoff["head_grads"] = (grads, c, p, nc)
             return (d_k, None) + _split_grads(grads, c, p, nc) + (None,) * 10
         kc, yc, bn_wc, bn_bc, w1c, w2c, mean, invstd, h1d, out, loss_partials, loss = ctx.saved_tensors
         g, c = kc.shape

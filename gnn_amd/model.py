@@ -80,7 +80,11 @@ class RW_NN(nn.Module):
         statistics (one launch less), see :func:`gnn_amd.function.rw_kernel_layer`."""
         if not (self.training and self._head_fusable(structure.n_graphs, self.hidden_graphs * self.max_step, drop)):
             return None
-        return {"head_drop": drop > 0.0}
+        handoff = {"head_drop": drop > 0.0}
+        tail = getattr(self, "_step_tail", None)
+        if tail is not None and tail.armed:   # gnn_amd.optim.StepTail: the optimiser's update in the last backward launch
+            handoff["tail"] = tail
+        return handoff
 
     def _head(self, k, drop, handoff=None):
         if self._use_fused_head(k, drop):

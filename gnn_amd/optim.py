@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from .dp import FlatGradBucket
 
-__all__ = ["FlatAdam"]
+__all__ = ["FlatAdam", "StepTail"]
 
 
 class FlatAdam:
@@ -77,3 +77,76 @@ class FlatAdam:
                                      self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.flat_param.numel(),
                                      self.lr.data_ptr(), self.betas[0], self.betas[1], self.eps, self.weight_decay,
                                      self.step_counters.data_ptr(), _lib.current_stream(dev)), "rwk_adam_step")
+
+
+class StepTail:
+    """The optimiser's update inside the backward pass's last launch (single-process training step).
+
+    ``RW_NN``'s backward ends with one small launch (hidden-graph backward + the input projection's gradient sum) and
+    the step with another (Adam over the flat buffer).  Adam is element-wise, so the threads of the former can apply
+    it to the gradient elements they finish and a few more workgroups to the head's parameters, whose gradients are
+    in memory by then (``rwk_hidden_backward_reduce_adam``): one launch less per step, the same arithmetic.
+
+    ``Trainer`` hands an instance to the model (``model._step_tail``); the model passes it down with the hand-off
+    dictionary, the head's backward leaves its gradient buffer there, and the layer's backward calls :meth:`launch`
+    in place of ``rwk_hidden_backward_reduce``.  ``done`` then tells the trainer to skip ``optimizer.step()``.
+    Requires the flat buffer to start with ``adj_hidden, features_hidden, fc.weight, fc.bias`` (``RW_NN``'s
+    parameter order) followed by the head's six tensors."""
+
+    def __init__(self, model, opt: FlatAdam):
+        self.opt = opt
+        self.done = False
+        self.armed = False        # set by the trainer around its own forward + backward only
+        params = opt.bucket.params
+        want = [model.adj_hidden, model.features_hidden, model.fc.weight, model.fc.bias, model.bn.weight,
+                model.bn.bias, model.fc1.weight, model.fc1.bias, model.fc2.weight, model.fc2.bias]
+        if len(params) != len(want) or any(a is not b for a, b in zip(params, want)):
+            raise ValueError("StepTail needs RW_NN's ten parameters, all trainable, in the module's order")
+        sizes = [p.numel() for p in params]
+        self.off_adj, self.off_feat, self.off_red = 0, sizes[0], sizes[0] + sizes[1]
+        self.red_v = sizes[2] + sizes[3]
+        self.rest_off = self.off_red + self.red_v
+        self.n = sum(sizes)
+        self.rest_sizes = sizes[4:]
+        lib = _lib.load()
+        n_hidden = model.adj_hidden.shape[0]
+        n_counters = int(lib.rwk_step_tail_n_counters(n_hidden, self.n, self.rest_off))
+        dev = opt.flat_param.device
+        # one counter per workgroup of either launch shape, all at the optimiser's step count: the two shapes may
+        # then alternate (the counters one shape does not touch are brought along by sync_counters)
+        self.counters = torch.zeros(max(n_counters, opt.step_counters.numel()), dtype=torch.int64, device=dev)
+        self.counters.copy_(opt.step_counters[:1].expand_as(self.counters))
+        opt.step_counters = self.counters
+
+    def sync_counters(self):
+        """After an update by the stand-alone Adam launch (which advances only its own workgroups' counters)."""
+        self.counters.copy_(self.counters[:1].expand_as(self.counters))
+
+    def head_sources(self, head_grads: torch.Tensor, c: int, p: int, nc: int):
+        """Device addresses of the gradients of bn.weight, bn.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias inside
+        the head's gradient buffer ([w2 | b2 | w1 | b1 | gamma | beta])."""
+        base, f = head_grads.data_ptr(), 4
+        o_w2, o_b2 = 0, nc * p
+        o_w1 = o_b2 + nc
+        o_b1 = o_w1 + p * c
+        o_ga = o_b1 + p
+        o_be = o_ga + c
+        if [c, c, p * c, p, nc * p, nc] != self.rest_sizes:
+            raise ValueError("head gradient buffer does not match the optimiser's parameter sizes")
+        return [base + f * o for o in (o_ga, o_be, o_w1, o_b1, o_w2, o_b2)]
+
+    def launch(self, lib, stream, head_srcs, adj_hidden, ah, z, dz, dz_rows, n_hidden, s, d, steps, d_adj, d_feat,
+               partials, blocks, red_v, red_out):
+        import ctypes
+        if red_v != self.red_v:
+            raise ValueError("projection gradient width does not match fc.weight and fc.bias")
+        o = self.opt
+        n = len(head_srcs)
+        srcs = (ctypes.c_void_p * n)(*head_srcs)
+        sizes = (ctypes.c_int64 * n)(*self.rest_sizes)
+        _lib.check(lib.rwk_hidden_backward_reduce_adam(
+            adj_hidden, ah, z, dz, dz_rows, n_hidden, s, d, steps, d_adj, d_feat, partials, blocks, red_v, red_out,
+            o.flat_param.data_ptr(), o.exp_avg.data_ptr(), o.exp_avg_sq.data_ptr(), o.bucket.flat.data_ptr(), self.n,
+            self.off_adj, self.off_feat, self.off_red, srcs, sizes, n, self.rest_off, o.lr.data_ptr(), o.betas[0],
+            o.betas[1], o.eps, o.weight_decay, self.counters.data_ptr(), stream), "rwk_hidden_backward_reduce_adam")
+        self.done = True

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from .dp import FlatGradBucket
 from .losses import cross_entropy
-from .optim import FlatAdam
+from .optim import FlatAdam, StepTail
 
 __all__ = ["Trainer"]
 
@@ -32,7 +32,7 @@ class Trainer:
 
     def __init__(self, model, batch_t, world: int = 1, optimizer: str = "flat", lr: float = 1e-2,
                  fused_loss: bool = True, capture_error_mode: str = None, sync_before_all_reduce: bool = False,
-                 forward_fn=None, capture_collective: bool = False):
+                 forward_fn=None, capture_collective: bool = False, merge_tail: bool = True):
         self.model = model
         self.adj, self.feats, self.gi, self.y = batch_t
         # forward_fn(): the model's scores for the resident batch, for models with another call signature than
@@ -52,6 +52,15 @@ class Trainer:
         self.loss_in_head = fused_loss and forward_fn is None and hasattr(model, "forward_with_loss")
         # one process, flat optimiser: the gradient gather rides in the Adam launch
         self.fused_gather = world == 1 and optimizer == "flat"
+        # ... and for RW_NN the Adam update itself rides in the backward pass's last launch (optim.StepTail), whenever
+        # the step takes the fused path (narrow inputs, hidden_dim 4, at least two steps, fused head with the loss)
+        self.tail = None
+        if merge_tail and self.fused_gather and self.loss_in_head:
+            try:
+                self.tail = StepTail(model, self.opt)
+                model._step_tail = self.tail
+            except (ValueError, AttributeError):
+                self.tail = None
         # gloo's all-reduce of a device tensor was seen to hang when the device still has queued work (two ranks on
         # one GPU, with or without graphs); rehearsals on that backend wait for the device first.  RCCL runs do not.
         self.sync_before_all_reduce = sync_before_all_reduce
@@ -71,12 +80,18 @@ class Trainer:
 
     def fwd_bwd(self):
         self.bucket.release()            # optimizer.zero_grad(set_to_none=True)
-        if self.loss_in_head:
-            _, self.loss = self.model.forward_with_loss(self.adj, self.feats, self.gi, self.y)
-        else:
-            out = self.forward_fn()
-            self.loss = self.loss_fn(out, self.y)
-        self.loss.backward(self._one)
+        if self.tail is not None:
+            self.tail.armed = True       # this backward pass ends with the optimiser's update
+        try:
+            if self.loss_in_head:
+                _, self.loss = self.model.forward_with_loss(self.adj, self.feats, self.gi, self.y)
+            else:
+                out = self.forward_fn()
+                self.loss = self.loss_fn(out, self.y)
+            self.loss.backward(self._one)
+        finally:
+            if self.tail is not None:
+                self.tail.armed = False
         if not self.fused_gather:
             self.bucket.gather()         # per-parameter gradients -> the flat bucket, one launch
 
@@ -92,8 +107,13 @@ class Trainer:
         self.bucket.all_reduce()
 
     def _opt_step(self):
+        if self.tail is not None and self.tail.done:      # the update rode in the backward pass's last launch
+            self.tail.done = False
+            return
         if self.fused_gather:
             self.opt.step(gather=True)
+            if self.tail is not None:
+                self.tail.sync_counters()
         else:
             self.opt.step()
 

@@ -407,6 +407,26 @@ int rwk_hidden_backward_reduce(const float *adj_hidden, const float *ah, const f
                                float *d_adj_hidden, float *d_features_hidden, const float *red_in, int64_t red_p,
                                int64_t red_v, float *red_out, rwk_stream_t stream);
 
+/* rwk_hidden_backward_reduce with the optimiser's update of every parameter inside: the last launch of a
+ * single-process training step (the end of the autograd backward of model.py:39-43,56 and optimizer.step() of
+ * rwgnn2/main.py:87 with torch.optim.Adam's arithmetic, as rwk_adam_step).  Adam is element-wise, so the thread
+ * that finishes a gradient element applies it: hidden graph h's workgroup updates its rows of adj_hidden and
+ * features_hidden, the column-sum workgroup the red_v values (fc.weight | fc.bias), further workgroups the n_rest
+ * remaining tensors, whose gradients rest_srcs[k] (rest_sizes[k] floats, NULL: zeros) an earlier launch left in memory.
+ * param / exp_avg / exp_avg_sq / grad_out (may be NULL: the flat gradient is not kept) are flat buffers of n floats
+ * holding adj_hidden at off_adj, features_hidden at off_feat, the column sums at off_red - together exactly
+ * [0, rest_off) - and the remaining tensors back to back in [rest_off, n).  step_counters:
+ * rwk_step_tail_n_counters(h, n, rest_off) int64 at one common step count (each workgroup advances its own). */
+int64_t rwk_step_tail_n_counters(int64_t h, int64_t n, int64_t rest_off);
+int rwk_hidden_backward_reduce_adam(const float *adj_hidden, const float *ah, const float *z, const float *dz_partials,
+                                    int64_t n_partials, int64_t h, int64_t s, int64_t d, int64_t max_step,
+                                    float *d_adj_hidden, float *d_features_hidden, const float *red_in, int64_t red_p,
+                                    int64_t red_v, float *red_out, float *param, float *exp_avg, float *exp_avg_sq,
+                                    float *grad_out, int64_t n, int64_t off_adj, int64_t off_feat, int64_t off_red,
+                                    const float *const *rest_srcs, const int64_t *rest_sizes, int64_t n_rest,
+                                    int64_t rest_off, const float *lr, float beta1, float beta2, float eps,
+                                    float weight_decay, int64_t *step_counters, rwk_stream_t stream);
+
 /* out[v] = sum_p in[p, v], rows added in a fixed order (p > 32: 32 row blocks of ceil(p/32) rows,
  * each summed by 4 interleaved slices, then the 32 block sums in index order; v <= 64 columns: one
  * launch, interleaved lanes per column and a halving tree), so the result is bitwise

@@ -128,6 +128,43 @@ def test_graph_replay_trains_like_eager(world, dev):
         assert rel_err(pg.detach().cpu().numpy(), pe.detach().cpu().numpy()) < 1e-3
 
 
+@pytest.mark.parametrize("drop", [0.0, 0.2])
+def test_optimiser_update_inside_the_last_backward_launch(dev, drop):
+    """Single-process step: the Adam update applied by the backward pass's last launch (optim.StepTail) against the
+    same step with the stand-alone Adam launch - parameters, both moment buffers, the flat gradient and the step
+    counters bit for bit after several steps, eagerly and replayed from a graph; the hand-over is armed only inside
+    the trainer's own step."""
+    c = GoldenCase("mutag_b0")
+    hp = dict(c.hp, dropout=drop)
+    merged, plain = _trainer(c, hp, dev), _trainer(c, hp, dev, merge_tail=False)
+    assert merged.tail is not None and plain.tail is None
+    for _ in range(4):
+        merged.step_eager()
+        plain.step_eager()
+        assert not merged.tail.done and not merged.tail.armed
+    assert int(merged.opt.step_counters.min()) == 4 and int(merged.opt.step_counters.max()) == 4
+    for a, b in ((merged.opt.flat_param, plain.opt.flat_param), (merged.opt.exp_avg, plain.opt.exp_avg),
+                 (merged.opt.exp_avg_sq, plain.opt.exp_avg_sq), (merged.bucket.flat, plain.bucket.flat)):
+        assert torch.equal(a, b)
+    assert float(merged.loss) == float(plain.loss)
+    merged.capture()                      # 3 more eager steps, then the captured one
+    for _ in range(3):
+        plain.step_eager()
+    for _ in range(3):
+        merged.step_graph()
+        plain.step_eager()
+    torch.cuda.synchronize()
+    assert int(merged.opt.step_counters.min()) == 10 and int(merged.opt.step_counters.max()) == 10
+    assert torch.equal(merged.opt.flat_param, plain.opt.flat_param)
+    assert torch.equal(merged.opt.exp_avg_sq, plain.opt.exp_avg_sq)
+    # outside the trainer's step the model's backward leaves the parameters alone
+    before = merged.opt.flat_param.clone()
+    _, loss = merged.model.forward_with_loss(merged.adj, merged.feats, merged.gi, merged.y)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(merged.opt.flat_param, before)
+
+
 def test_data_parallel_step_with_captured_collective_slot(dev):
     """The data-parallel step with the all-reduce inside the step's graph (one replay per step): on one device
     without a process group the collective is a no-op, which exercises the capture, its self-check and the replay;
