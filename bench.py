@@ -180,7 +180,7 @@ def time_kernels(batch_t, hp, budget_ms=150.0, only=None):
         e1.record()
         torch.cuda.synchronize()
         one = max(e0.elapsed_time(e1), 1e-3)
-        iters = int(min(50, max(3, budget_ms / one)))
+        iters = int(min(400, max(3, budget_ms / one)))
         for _ in range(min(5, iters)):
             fn()
         e0.record()
@@ -411,18 +411,33 @@ def main():
     else:
         step = tr.step_eager
 
+    # The per-kernel timings of the roofline entry run before the timed steps, not after: they keep the device busy
+    # for some 25 ms, and the step needs ~10 ms of load to reach its steady duration (the first 80 replays after an
+    # idle period were measured up to 4 % slower, which a 20-step timed region would otherwise report as the step
+    # time).
+    kern = None
+    if rank == 0 and not args.no_kernel_timing:
+        kern = time_kernels(batch_t, hp)
     for _ in range(args.warmup):
         step()
     if world > 1:
         dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(args.steps):
         step()
+    ev1.record()
+    # the host polls for the end of the last step (a blocking wait is woken tens of microseconds late, which a short
+    # timed region would carry as step time); the synchronize below then returns at once
+    while not ev1.query():
+        pass
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    device_ms = ev0.elapsed_time(ev1)
     n_graphs_total = batch.n_graphs
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -458,6 +473,8 @@ def main():
                 "parallelism": f"dp{world} (graphs sharded, one flat-bucket all-reduce)",
             },
             "final_loss": round(loss, 5),
+            # the same K steps between two events on the launch stream (rank 0): what the host clock adds
+            "device_ms_per_step": round(device_ms / args.steps, 4),
         }
         if shape_world != world:
             result["config"]["launch"] += f"; step in the shape of a {shape_world}-rank run (no process group)"
@@ -465,8 +482,7 @@ def main():
             result["phases"] = phases
         if tr.capture_note:
             result["config"]["launch"] += "; " + tr.capture_note
-        if not args.no_kernel_timing:
-            kern = time_kernels(batch_t, hp)
+        if kern is not None:
             result["kernel_shape"] = kern.pop("_shape")
             dom = max(kern, key=lambda k: kern[k]["us"])
             traffic = load_traffic(args.config, 1)

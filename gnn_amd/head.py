@@ -168,6 +168,9 @@ class _FusedHeadLoss(torch.autograd.Function):
             raise ValueError("labels must be an int64 tensor of one class index per graph on the device of k")
         drop = float(drop_p) if (training and drop_p and rng_state is not None) else 0.0
         check_labels(labels, nc)
+        # `out` is marked non-differentiable below; autograd would still hand backward() a zero tensor of its shape
+        # (a fill launch per step) unless told not to materialise undefined gradients
+        ctx.set_materialize_grads(False)
         # grad_mode: the caller's torch.is_grad_enabled() (inside forward() it is always off, and
         # needs_input_grad reports requires_grad of the inputs whatever the mode)
         needs_grad = bool(grad_mode) and any(ctx.needs_input_grad[:1] + ctx.needs_input_grad[2:8])
@@ -228,6 +231,8 @@ class _FusedHeadLoss(torch.autograd.Function):
     def backward(ctx, _d_out, d_loss):
         lib = _lib.load()
         training, drop, train_fused = ctx.cfg
+        if d_loss is None:                                # nothing downstream used the loss
+            return (None,) * 18
         if train_fused:
             kc, bn_wc, mean, invstd, dy, partials, loss_partials, loss = ctx.saved_tensors
             g, c = kc.shape
