@@ -51,6 +51,9 @@ def parse_args():
                     help="replay the step from a captured HIP graph (default) or launch it eagerly")
     ap.add_argument("--optimizer", choices=["flat", "torch"], default="flat",
                     help="flat: gnn_amd.optim.FlatAdam (one launch); torch: torch.optim.Adam(capturable)")
+    ap.add_argument("--steps-per-graph", type=int, default=5,
+                    help="graph mode, one process: consecutive steps captured in one graph (whole replays first, the "
+                         "remaining steps as single-step replays); 1 = one step per replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-sample-graphs", type=int, default=1024)
@@ -398,10 +401,15 @@ def main():
     tr = Trainer(model, batch_t, shape_world, args.optimizer, sync_before_all_reduce=backend != "nccl",
                  capture_collective=capture_collective and world > 1)
     launch = args.mode
+    run_steps = None
     if args.mode == "graph":
         try:
-            tr.capture()
+            spg = args.steps_per_graph if (shape_world == 1 and args.steps_per_graph > 1) else 1
+            tr.capture(steps_per_graph=spg)
             step = tr.step_graph
+            if tr.multi_k > 1:
+                run_steps = tr.run_steps
+                launch = "graph (%d steps per replay)" % tr.multi_k
         except Exception as exc:        # a capture that the runtime refuses must not cost the whole measurement
             print(f"[bench] HIP-graph capture failed ({type(exc).__name__}: {exc}); launching eagerly",
                   file=sys.stderr, flush=True)
@@ -418,16 +426,22 @@ def main():
     kern = None
     if rank == 0 and not args.no_kernel_timing:
         kern = time_kernels(batch_t, hp)
-    for _ in range(args.warmup):
-        step()
+    if run_steps is not None:
+        run_steps(args.warmup)
+    else:
+        for _ in range(args.warmup):
+            step()
     if world > 1:
         dist.barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
-        step()
+    if run_steps is not None:
+        run_steps(args.steps)
+    else:
+        for _ in range(args.steps):
+            step()
     ev1.record()
     # the host polls for the end of the last step (a blocking wait is woken tens of microseconds late, which a short
     # timed region would carry as step time); the synchronize below then returns at once

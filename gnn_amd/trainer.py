@@ -77,6 +77,10 @@ class Trainer:
         self._one = torch.ones((), dtype=torch.float32, device=self.y.device)
         self.g_fb = None
         self.g_opt = None
+        self.g_multi = None
+        self.multi_k = 1
+        self.losses = []
+        self._single_loss = None
 
     def fwd_bwd(self):
         self.bucket.release()            # optimizer.zero_grad(set_to_none=True)
@@ -117,12 +121,19 @@ class Trainer:
         else:
             self.opt.step()
 
-    def capture(self):
+    def capture(self, steps_per_graph: int = 1):
         """Capture the step as HIP graphs.  One process: one graph.  Data parallel: forward+backward and the Adam
         update as two graphs with the (tiny) gradient all-reduce an ordinary RCCL call on the same stream between
         them - or, with ``capture_collective``, the all-reduce inside a single graph when the collective library
         accepts being captured (checked by replaying it once against the eager collective; any refusal or mismatch
-        falls back to the two-graph shape and is recorded in ``capture_note``)."""
+        falls back to the two-graph shape and is recorded in ``capture_note``).
+
+        ``steps_per_graph`` > 1 (one process): a second graph holds that many consecutive steps, for
+        :meth:`run_steps`.  Starting a replay costs about as much as four kernel boundaries inside one (7.5 us
+        against 1.75 us on an MI355X), so a loop that replays several steps at a time - an epoch's batches in the
+        reference's loop, ``main.py:103-106`` - pays it once per replay instead of once per step.  Everything a step
+        carries over (parameters, moments, step count, dropout generator state, running statistics) lives on the
+        device, so the result is the same as that many single-step replays."""
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -143,10 +154,24 @@ class Trainer:
             self.fwd_bwd()
             if self.world == 1:          # nothing happens between backward and the update: one graph
                 self._opt_step()
+        self._single_loss = self.loss = self.loss.detach()   # same storage, without the captured autograd graph
         if self.world > 1:
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt, capture_error_mode=self.capture_error_mode):
                 self._opt_step()
+        elif steps_per_graph > 1:
+            g_multi, losses = torch.cuda.CUDAGraph(), []
+            try:
+                with torch.cuda.graph(g_multi, capture_error_mode=self.capture_error_mode):
+                    for _ in range(steps_per_graph):
+                        self.fwd_bwd()
+                        self._opt_step()
+                        losses.append(self.loss.detach())
+                self.g_multi, self.losses, self.multi_k = g_multi, losses, int(steps_per_graph)
+            except Exception as exc:      # the single-step graph stays usable
+                torch.cuda.synchronize()
+                self.capture_note = "multi-step capture refused (%s: %s)" % (type(exc).__name__, str(exc)[:200])
+            self.loss = self._single_loss  # step_graph() leaves its loss here; run_steps() points it at the last one
 
     def _capture_single_graph(self) -> bool:
         """forward+backward, all-reduce and update in one graph.  Returns False (with everything as it was before,
@@ -187,6 +212,24 @@ class Trainer:
         if self.world > 1 and not self.collective_captured:
             self._all_reduce()
             self.g_opt.replay()
+
+    def run_steps(self, n: int):
+        """``n`` training steps: whole multi-step replays first (``capture(steps_per_graph=k)``), then single ones.
+        ``self.loss`` is the loss of the last step run; ``self.losses`` those of the last multi-step replay."""
+        k = self.multi_k
+        last_multi = False
+        if k > 1:
+            while n >= k:
+                self.g_multi.replay()
+                n -= k
+                last_multi = True
+        if n > 0:
+            if self._single_loss is not None:
+                self.loss = self._single_loss
+            for _ in range(n):
+                self.step_graph()
+        elif last_multi:
+            self.loss = self.losses[-1]
 
     def phase_times(self, steps: int = 30):
         """Median device time (ms) of the phases of the replayed step, from events on the launch stream, and the

@@ -129,6 +129,39 @@ def test_graph_replay_trains_like_eager(world, dev):
 
 
 @pytest.mark.parametrize("drop", [0.0, 0.2])
+def test_multi_step_graph_equals_single_step_replays(dev, drop):
+    """A graph that holds three consecutive steps (Trainer.capture(steps_per_graph=3), run_steps) against the same
+    number of single-step replays: parameters, moments, step counters, running statistics, generator state and the
+    losses bit for bit - with dropout too, its generator state advancing on the device inside the graph."""
+    c = GoldenCase("mutag_b0")
+    hp = dict(c.hp, dropout=drop)
+    multi, single = _trainer(c, hp, dev), _trainer(c, hp, dev)
+    multi.capture(steps_per_graph=3)
+    single.capture()
+    assert multi.multi_k == 3 and single.multi_k == 1
+    multi.run_steps(8)                    # two replays of three steps, two single replays
+    singles = []
+    for _ in range(8):
+        single.step_graph()
+        singles.append(float(single.loss))
+    torch.cuda.synchronize()
+    assert float(multi.loss) == singles[-1]
+    multi.run_steps(3)                    # ends on a multi-step replay
+    for _ in range(3):
+        single.step_graph()
+        singles.append(float(single.loss))
+    torch.cuda.synchronize()
+    assert [float(v) for v in multi.losses] == singles[-3:] and float(multi.loss) == singles[-1]
+    for a, b in ((multi.opt.flat_param, single.opt.flat_param), (multi.opt.exp_avg, single.opt.exp_avg),
+                 (multi.opt.exp_avg_sq, single.opt.exp_avg_sq), (multi.opt.step_counters, single.opt.step_counters),
+                 (multi.model._rng_state, single.model._rng_state),
+                 (multi.model.bn.running_mean, single.model.bn.running_mean),
+                 (multi.model.bn.running_var, single.model.bn.running_var),
+                 (multi.model.bn.num_batches_tracked, single.model.bn.num_batches_tracked)):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.2])
 def test_optimiser_update_inside_the_last_backward_launch(dev, drop):
     """Single-process step: the Adam update applied by the backward pass's last launch (optim.StepTail) against the
     same step with the stand-alone Adam launch - parameters, both moment buffers, the flat gradient and the step
