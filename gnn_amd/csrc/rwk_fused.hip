@@ -677,6 +677,48 @@ int rwk_fused_backward(const float *x, const float *z, const int32_t *gid, const
     }
 }
 
+int rwk_fused_backward_bn_supported(int64_t d, int64_t h, int64_t s, int64_t max_step) {
+    return rwk_reg::bn_fold_supported(d, h, s, max_step) ? 1 : 0;
+}
+
+int rwk_fused_backward_bn(const float *x, const float *z, const int32_t *gid, const int32_t *perm,
+                          const float *counts_f32, int64_t n, int64_t d, int64_t h, int64_t s, int64_t max_step,
+                          int64_t stream_len, float drop_p, int normalize, const uint64_t *rng, float *dx,
+                          float *dz_partials, const float *k, const float *dy, const float *mean, const float *invstd,
+                          const float *bn_w, const float *head_partials, int64_t n_head_partials, int64_t head_nv,
+                          int64_t o_gamma, const float *d_loss, int64_t n_graphs, rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(x);
+    RWK_REQUIRE_PTR(z);
+    RWK_REQUIRE_PTR(gid);
+    RWK_REQUIRE_PTR(dx);
+    RWK_REQUIRE_PTR(dz_partials);
+    RWK_REQUIRE_PTR(k);
+    RWK_REQUIRE_PTR(dy);
+    RWK_REQUIRE_PTR(mean);
+    RWK_REQUIRE_PTR(invstd);
+    RWK_REQUIRE_PTR(bn_w);
+    RWK_REQUIRE_PTR(head_partials);
+    RWK_REQUIRE_PTR(d_loss);
+    if (normalize) RWK_REQUIRE_PTR(counts_f32);
+    if (!sizes_ok(n, d, h, s, max_step, stream_len) || !(drop_p >= 0.f && drop_p < 1.f)) return RWK_E_SIZE;
+    if (!rwk_reg::bn_fold_supported(d, h, s, max_step)) return RWK_E_UNSUPPORTED;
+    const int64_t c = max_step * h;
+    if (n_graphs <= 0 || n_head_partials <= 0 || n_head_partials > 0x7FFFFFFF || head_nv <= 0 ||
+        head_nv > 0x7FFFFFFF || o_gamma < 0 || o_gamma + 2 * c > head_nv)
+        return RWK_E_SIZE;
+    rwk_reg::Args r{};
+    r.x = x; r.z = z; r.gid = gid; r.perm = perm;
+    r.n = (int)n; r.d = (int)d; r.h = (int)h; r.s = (int)s; r.max_step = (int)max_step;
+    r.stream_len = (int)stream_len; r.drop = drop_p > 0.f && rng != nullptr; r.rng = (const unsigned long long *)rng;
+    r.stream = (hipStream_t)stream; r.d_k = nullptr; r.counts_f32 = counts_f32;
+    r.scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f; r.normalize = normalize;
+    r.dx = dx; r.dz_partials = dz_partials;
+    r.bn = rwk_reg::BnFold{k, dy, mean, invstd, bn_w, head_partials, d_loss, (int)n_head_partials, (int)head_nv,
+                           (int)o_gamma, 1.f / (float)n_graphs};
+    rwk_drop_thresholds(drop_p, &r.t0, &r.t1);
+    return rwk_reg::backward(r);
+}
+
 int rwk_fused_keep_s_supported(int64_t d, int64_t h, int64_t s, int64_t max_step) {
     return rwk_reg::keep_s_supported(d, h, s, max_step) ? 1 : 0;
 }

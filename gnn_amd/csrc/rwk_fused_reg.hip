@@ -10,6 +10,7 @@
 // LDS is touched once, at the end of the backward kernel, to add the lanes that own the same hidden
 // graph in a fixed order.
 #include "rwk_fused_reg.h"
+#include "rwk_head_partials.h"
 
 namespace rwk_reg {
 namespace {
@@ -319,16 +320,30 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                 const int *__restrict__ perm, const float *__restrict__ d_k, const float *__restrict__ counts_f32,
                 int n, int d, int h, int stream_len, int hp_arg, int prio, float scale, int normalize,
                 uint32_t t0, uint32_t t1, const unsigned long long *__restrict__ rng, float *__restrict__ dx,
-                float *__restrict__ dz_partials) {
+                float *__restrict__ dz_partials, BnFold bn) {
     constexpr int NC = (LT * ST + 14) / 15;
     const int hp = HPT ? HPT : hp_arg;
     constexpr int V = LT * ST * DP;               // gradient values per lane
     constexpr int CH = V < 16 ? V : 16;           // values staged per LDS round of the final reduction
     __shared__ Tile<LT> tiles[2];                 // tile t in tiles[t & 1]; the other one is being filled
     __shared__ float red[CH][kBlock];
+    __shared__ float s_bn[64];                    // folded batch-norm backward: [dgamma sums | dbeta sums], times d_loss
 
     RWK_STAMP_DECL();
     const int tid = threadIdx.x;
+    // folded batch-norm backward (never with KS): the 2c column sums of the head's partial rows, requested before
+    // anything else is waited for and added in the order of the head's own finishing kernel (8 lanes per column,
+    // rows lane8, lane8 + 8, ..., then the eight lanes)
+    const bool fold = !KS && bn.partials != nullptr;
+    RwkFinPartials bn_pre[2];
+    const int bn_c = LT * h;
+    if (fold) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int q = it * (kBlock / 8) + (tid >> 3);
+            bn_pre[it].load(bn.partials, bn.n_partials, bn.nv, bn.o_ga + (q < 2 * bn_c ? q : 2 * bn_c - 1), tid & 7);
+        }
+    }
     const int lane_h = tid % hp;
     const int hh = lane_h < h ? lane_h : h - 1;
     const bool own_h = lane_h < h;
@@ -364,6 +379,18 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
         const int idx = rwk_halving_index<(LT == 4 ? 16 : 8)>(lane_h);
         red_off = (((idx / DP) % LT) * kBlock + group0) * DP + idx % DP;      // in floats from &tile.x[0][0]
     }
+    float bn_dl = 1.f;
+    if (fold) {
+        bn_dl = bn.d_loss[0];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int q = it * (kBlock / 8) + (tid >> 3);
+            float acc = bn_pre[it].sum(bn.partials, bn.n_partials, bn.nv, bn.o_ga + (q < 2 * bn_c ? q : 2 * bn_c - 1),
+                                       tid & 7);
+            acc = rwk_group_sum(acc, 8);
+            if ((tid & 7) == 0 && q < 2 * bn_c) s_bn[q < bn_c ? q : 32 + (q - bn_c)] = acc * bn_dl;
+        }
+    }
     put_slot<LT>(tiles[0], slot, has_stream);
     __syncthreads();
     ProgressPriority priority(prio, stream_len);
@@ -394,11 +421,32 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                 g_cur = g;
                 float f = scale;
                 if (normalize) f /= counts_f32[g];
+                if (fold) {
+                    // this lane's elements of d(loss)/d(K[g]) from the head's intermediates (every load independent)
+                    float e_dy[LT], e_k[LT], e_mu[LT], e_is[LT], e_w[LT];
 #pragma unroll
-                for (int i = 0; i < LT; ++i)
+                    for (int i = 0; i < LT; ++i) {
+                        const int col = i * h + hh;
+                        e_dy[i] = bn.dy[(size_t)g * lh + col];
+                        e_k[i] = bn.k[(size_t)g * lh + col];
+                        e_mu[i] = bn.mean[col];
+                        e_is[i] = bn.invstd[col];
+                        e_w[i] = bn.bn_w[col];
+                    }
 #pragma unroll
-                    for (int q = 0; q < SK; ++q)
-                        dp_cur[i][q] = own_h ? d_k[((size_t)g * lh + i * h + lane_h) * SK + q] * f : 0.f;
+                    for (int i = 0; i < LT; ++i) {
+                        const int col = i * h + hh;
+                        const float dk = rwk_bn_input_grad(e_dy[i], e_k[i], e_mu[i], e_is[i], e_w[i] * e_is[i],
+                                                           s_bn[col], s_bn[32 + col], bn.inv_g, bn_dl, true);
+                        dp_cur[i][0] = own_h ? dk * f : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < LT; ++i)
+#pragma unroll
+                        for (int q = 0; q < SK; ++q)
+                            dp_cur[i][q] = own_h ? d_k[((size_t)g * lh + i * h + lane_h) * SK + q] * f : 0.f;
+                }
             }
             // no validity branch: a slot past the end of the stream has x = 0, so zx = t = 0 and every
             // product below is zero
@@ -546,18 +594,18 @@ int launch_bwd(const Args &a) {
 #define RWK_BWD(DROPV, HPV)                                                                                        \
     hipLaunchKernelGGL((backward_kernel<LT, ST, DROPV, HPV>), grid, dim3(kBlock), 0, a.stream, a.x, a.z, a.gid, a.perm, \
                        a.d_k, a.counts_f32, a.n, a.d, a.h, a.stream_len, hp, prio, a.scale, a.normalize, a.t0, a.t1, a.rng, \
-                       a.dx, a.dz_partials)
+                       a.dx, a.dz_partials, a.bn)
     if (a.keep_s) {
         if constexpr (keep_s_built(LT, ST)) {
             if (hp != 16) return RWK_E_UNSUPPORTED;
             if (a.drop)
                 hipLaunchKernelGGL((backward_kernel<LT, ST, true, 16, true>), grid, dim3(kBlock), 0, a.stream, a.x, a.z,
                                    a.gid, a.perm, a.d_k, a.counts_f32, a.n, a.d, a.h, a.stream_len, hp, prio, a.scale,
-                                   a.normalize, a.t0, a.t1, a.rng, a.dx, a.dz_partials);
+                                   a.normalize, a.t0, a.t1, a.rng, a.dx, a.dz_partials, a.bn);
             else
                 hipLaunchKernelGGL((backward_kernel<LT, ST, false, 16, true>), grid, dim3(kBlock), 0, a.stream, a.x,
                                    a.z, a.gid, a.perm, a.d_k, a.counts_f32, a.n, a.d, a.h, a.stream_len, hp, prio, a.scale,
-                                   a.normalize, a.t0, a.t1, a.rng, a.dx, a.dz_partials);
+                                   a.normalize, a.t0, a.t1, a.rng, a.dx, a.dz_partials, a.bn);
         } else {
             return RWK_E_UNSUPPORTED;
         }
@@ -597,6 +645,10 @@ int by_l(const Args &a, bool bwd) {
 bool supported(int64_t d, int64_t h, int64_t s, int64_t max_step) {
     if (d < 1 || d > DP || h < 1 || h > 64 || max_step < 1 || max_step > 4) return false;
     return s == 1 || s == 3 || s == 4 || s == 5 || s == 6 || s == 8 || s == 10;
+}
+
+bool bn_fold_supported(int64_t d, int64_t h, int64_t s, int64_t max_step) {
+    return supported(d, h, s, max_step) && max_step * h <= 32;     // the 2c column sums fit the kernel's 64 slots
 }
 
 bool keep_s_supported(int64_t d, int64_t h, int64_t s, int64_t max_step) {

@@ -11,6 +11,7 @@
 //
 // Rows are processed in tiles of kRows; a block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...
 #include "rwk_common.h"
+#include "rwk_head_partials.h"
 
 namespace {
 
@@ -1460,53 +1461,6 @@ head_train32_kernel(const float *__restrict__ k, HeadDims dm, const float *__res
     HEAD_STAMP_AT(27);
 }
 
-// The first 128 block partials of one element, fetched ahead of their use: lane8 holds blocks lane8, lane8 + 8, ...
-// sum() adds them in sum_partials8's order (and goes on with any further blocks as it does).
-struct FinPartials {
-    float v[16];
-    __device__ inline void load(const float *__restrict__ partials, int n_partials, int nv, int e, int lane8) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int b = lane8 + 8 * u;
-            v[u] = partials[(size_t)(b < n_partials ? b : n_partials - 1) * nv + e];
-        }
-    }
-    __device__ inline float sum(const float *__restrict__ partials, int n_partials, int nv, int e, int lane8) const {
-        float acc = 0.f;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) acc += lane8 + 8 * u < n_partials ? v[u] : 0.f;
-        for (int b0 = lane8 + 128; b0 < n_partials; b0 += 64) {
-            float w[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int b = b0 + 8 * u;
-                w[u] = partials[(size_t)(b < n_partials ? b : n_partials - 1) * nv + e];
-                if (b >= n_partials) w[u] = 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc += w[u];
-        }
-        return acc;
-    }
-};
-
-// partials[b][e] added over b = lane8, lane8 + 8, ... in that order, eight loads in flight at a time
-__device__ inline float sum_partials8(const float *__restrict__ partials, int n_partials, int nv, int e, int lane8) {
-    float acc = 0.f;
-    for (int b0 = lane8; b0 < n_partials; b0 += 64) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int b = b0 + 8 * u;
-            v[u] = partials[(size_t)(b < n_partials ? b : n_partials - 1) * nv + e];
-            if (b >= n_partials) v[u] = 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u];
-    }
-    return acc;
-}
-
 // ---------------------------------------------------------------------------------------------------
 // backward, second launch: parameter gradients (block partials added in block order) and dK
 // ---------------------------------------------------------------------------------------------------
@@ -1553,7 +1507,7 @@ head_bwd_finish_kernel(const float *__restrict__ k, HeadDims dm, const float *__
     const int e_lo = blockIdx.x * per, e_hi = e_lo + per < nv ? e_lo + per : nv;
     const int n_cols2 = d_k != nullptr ? 2 * c : 0;
     const long long n_tiles = (dm.g + kRows - 1) / kRows;
-    FinPartials pre_e, pre_c[2];
+    RwkFinPartials pre_e, pre_c[2];
     if (e_lo < e_hi) pre_e.load(partials, n_partials, nv, e_lo + grp < e_hi ? e_lo + grp : e_hi - 1, lane8);
 #pragma unroll
     for (int it = 0; it < 2; ++it)
@@ -1578,7 +1532,7 @@ head_bwd_finish_kernel(const float *__restrict__ k, HeadDims dm, const float *__
         const int e = e0 + grp;
         const int ec = e < e_hi ? e : e_hi - 1;
         float acc = e0 == e_lo ? pre_e.sum(partials, n_partials, nv, ec, lane8)
-                               : sum_partials8(partials, n_partials, nv, ec, lane8);
+                               : rwk_sum_partials8(partials, n_partials, nv, ec, lane8);
         acc = rwk_group_sum(acc, 8);
         if (lane8 == 0 && e < e_hi) grads[e] = acc * dl;
     }
@@ -1592,7 +1546,7 @@ head_bwd_finish_kernel(const float *__restrict__ k, HeadDims dm, const float *__
         float acc;
         if (c0 == 0) acc = pre_c[0].sum(partials, n_partials, nv, o_ga + qc, lane8);
         else if (c0 == kBlock / 8) acc = pre_c[1].sum(partials, n_partials, nv, o_ga + qc, lane8);
-        else acc = sum_partials8(partials, n_partials, nv, o_ga + qc, lane8);
+        else acc = rwk_sum_partials8(partials, n_partials, nv, o_ga + qc, lane8);
         acc = rwk_group_sum(acc, 8);
         if (lane8 == 0 && q < 2 * c) {
             if (q < c) s_dga[q] = acc * dl; else s_dbe[q - c] = acc * dl;
@@ -1609,12 +1563,8 @@ head_bwd_finish_kernel(const float *__restrict__ k, HeadDims dm, const float *__
             const bool pre = t == (long long)blockIdx.x && i == tid;
             const float is = pre ? t_is : invstd[col];
             const float sc = pre ? t_sc : bn_w[col] * is;
-            float v = (pre ? t_dy : dy[at]) * dl;
-            if (training) {
-                const float xh = ((pre ? t_k : k[at]) - (pre ? t_mu : mean[col])) * is;
-                v = v - s_dbe[col] * inv_g - xh * s_dga[col] * inv_g;
-            }
-            d_k[at] = v * sc;
+            d_k[at] = rwk_bn_input_grad(pre ? t_dy : dy[at], pre ? t_k : k[at], pre ? t_mu : mean[col], is, sc,
+                                        s_dga[col], s_dbe[col], inv_g, dl, training != 0);
         }
     }
     finish_loss();

@@ -6,6 +6,7 @@
 #include "rwk_hidden_body.h"
 #include "rwk_project_body.h"
 #include "rwk_reduce_body.h"
+#include "rwk_head_partials.h"
 
 namespace {
 
@@ -83,6 +84,21 @@ struct AdamTailArgs {
     long long off[kTailChunks];                          // flat index each chunk starts at; unused: LLONG_MAX
 };
 
+// The head's parameter gradients summed here instead of by the head's own finishing launch (partials == nullptr:
+// off, the chunk sources are finished gradient vectors).  The chunk sources then point into row 0 of `partials`
+// (n_partials rows of nv floats, the per-workgroup sums of the head's training kernel for d(loss) = 1); an element is
+// served by eight lanes, which add its rows in the order of the head's finishing kernel, and takes the factor d_loss.
+struct HeadSumArgs {
+    const float *partials;
+    int n_partials, nv;
+    const float *d_loss;
+    float *grads_out;                 // nv floats, or null
+    const float *loss_partials;       // n_partials per-workgroup sums of -log p(label), or null
+    float *loss_out;                  // their sum / n_graphs
+    long long n_graphs;
+};
+constexpr int kHeadSumPerBlock = kBlock / 8;
+
 __device__ inline double pow_int(double b, long long t) {
     double r = 1.0;
     while (t > 0) {
@@ -122,7 +138,8 @@ hidden_backward_reduce_adam_kernel(const float *__restrict__ adj_hidden, const f
                                    const float *__restrict__ z, const float *__restrict__ dz_partials, int n_partials,
                                    int n_hidden, int s, int d, int max_step, float *__restrict__ d_adj_hidden,
                                    float *__restrict__ d_feat_hidden, int n_slices, const float *__restrict__ red_in,
-                                   int red_p, int red_v, int red_vp, float *__restrict__ red_out, AdamTailArgs a) {
+                                   int red_p, int red_v, int red_vp, float *__restrict__ red_out, AdamTailArgs a,
+                                   HeadSumArgs hs) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float corr[2];
     if (threadIdx.x == 0) {
@@ -138,7 +155,7 @@ hidden_backward_reduce_adam_kernel(const float *__restrict__ adj_hidden, const f
                              d_adj_hidden, d_feat_hidden, n_slices, HiddenAdamTail{a, corr});
     } else if (b == n_hidden) {
         reduce_rows_small256_body(lds, red_in, red_p, red_v, red_vp, red_out, SumAdamTail{a, corr});
-    } else {
+    } else if (hs.partials == nullptr) {
         const long long i = a.rest_off + (long long)(b - n_hidden - 1) * kBlock + threadIdx.x;
         const long long ic = i < a.n ? i : a.n - 1;
         const float *src = a.src[0];
@@ -152,6 +169,49 @@ hidden_backward_reduce_adam_kernel(const float *__restrict__ adj_hidden, const f
         const float g = src ? src[ic - base] : 0.f;
         __syncthreads();
         if (i < a.n) adam_element(a, corr, i, g);
+    } else {
+        const int tid = threadIdx.x, lane8 = tid & 7, grp = tid >> 3;
+        const long long i = a.rest_off + (long long)(b - n_hidden - 1) * kHeadSumPerBlock + grp;
+        const long long ic = i < a.n ? i : a.n - 1;
+        const float *src = a.src[0];
+        long long base = a.off[0];
+#pragma unroll
+        for (int k = 1; k < kTailChunks; ++k) {
+            const bool ge = ic >= a.off[k];
+            src = ge ? a.src[k] : src;
+            base = ge ? a.off[k] : base;
+        }
+        const int e = src ? (int)(src - hs.partials) + (int)(ic - base) : 0;      // column of the partial rows
+        RwkFinPartials pre;
+        pre.load(hs.partials, hs.n_partials, hs.nv, e, lane8);
+        // mean loss, by the first wavefront of the last workgroup: lane l adds workgroups l, l + 64, ... in order, then
+        // a butterfly whose operand pairs are fixed (the head's finishing kernel, operation for operation)
+        const bool loss_wave = hs.loss_out != nullptr && blockIdx.x == gridDim.x - 1 && tid < 64;
+        float loss_v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (loss_wave) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = tid + 64 * u;
+                loss_v[u] = hs.loss_partials[q < hs.n_partials ? q : hs.n_partials - 1];
+            }
+        }
+        const float dl = hs.d_loss[0];
+        float acc = pre.sum(hs.partials, hs.n_partials, hs.nv, e, lane8);
+        acc = rwk_group_sum(acc, 8);
+        const float g = src ? acc * dl : 0.f;
+        __syncthreads();
+        if (lane8 == 0 && i < a.n) {
+            if (hs.grads_out != nullptr && src) hs.grads_out[e] = g;
+            adam_element(a, corr, i, g);
+        }
+        if (loss_wave) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (tid + 64 * u >= hs.n_partials) loss_v[u] = 0.f;
+            float lacc = ((loss_v[0] + loss_v[1]) + loss_v[2]) + loss_v[3];
+            for (int off = 32; off >= 1; off >>= 1) lacc += __shfl_xor(lacc, off, 64);
+            if (tid == 0) hs.loss_out[0] = lacc / (float)hs.n_graphs;
+        }
     }
 }
 
@@ -209,14 +269,19 @@ int64_t rwk_step_tail_n_counters(int64_t h, int64_t n, int64_t rest_off) {
     return h + 1 + rwk_ceil_div(n - rest_off, kBlock);
 }
 
-int rwk_hidden_backward_reduce_adam(const float *adj_hidden, const float *ah, const float *z, const float *dz_partials,
-                                    int64_t n_partials, int64_t h, int64_t s, int64_t d, int64_t max_step,
-                                    float *d_adj_hidden, float *d_features_hidden, const float *red_in, int64_t red_p,
-                                    int64_t red_v, float *red_out, float *param, float *exp_avg, float *exp_avg_sq,
-                                    float *grad_out, int64_t n, int64_t off_adj, int64_t off_feat, int64_t off_red,
-                                    const float *const *rest_srcs, const int64_t *rest_sizes, int64_t n_rest,
-                                    int64_t rest_off, const float *lr, float beta1, float beta2, float eps,
-                                    float weight_decay, int64_t *step_counters, rwk_stream_t stream_) {
+int64_t rwk_step_tail_n_counters_head(int64_t h, int64_t n, int64_t rest_off) {
+    if (h <= 0 || n <= 0 || rest_off < 0 || rest_off > n) return 0;
+    return h + 1 + rwk_ceil_div(n - rest_off, kHeadSumPerBlock);
+}
+
+static int step_tail_launch(const float *adj_hidden, const float *ah, const float *z, const float *dz_partials,
+                            int64_t n_partials, int64_t h, int64_t s, int64_t d, int64_t max_step,
+                            float *d_adj_hidden, float *d_features_hidden, const float *red_in, int64_t red_p,
+                            int64_t red_v, float *red_out, float *param, float *exp_avg, float *exp_avg_sq,
+                            float *grad_out, int64_t n, int64_t off_adj, int64_t off_feat, int64_t off_red,
+                            const float *const *rest_srcs, const int64_t *rest_sizes, int64_t n_rest,
+                            int64_t rest_off, const float *lr, float beta1, float beta2, float eps,
+                            float weight_decay, int64_t *step_counters, const HeadSumArgs &hs, rwk_stream_t stream_) {
     RWK_REQUIRE_PTR(adj_hidden);
     RWK_REQUIRE_PTR(ah);
     RWK_REQUIRE_PTR(z);
@@ -266,13 +331,61 @@ int rwk_hidden_backward_reduce_adam(const float *adj_hidden, const float *ah, co
     if (lds < kBlock * sizeof(float)) lds = kBlock * sizeof(float);
     const int rc = allow_lds(hidden_backward_reduce_adam_kernel, lds);
     if (rc != RWK_OK) return rc;
-    const unsigned grid = (unsigned)rwk_step_tail_n_counters(h, n, rest_off);
+    const unsigned grid = (unsigned)(hs.partials != nullptr ? rwk_step_tail_n_counters_head(h, n, rest_off)
+                                                            : rwk_step_tail_n_counters(h, n, rest_off));
     hipLaunchKernelGGL(hidden_backward_reduce_adam_kernel, dim3(grid), dim3(kBlock), lds, (hipStream_t)stream_,
                        adj_hidden, ah, z, dz_partials, (int)n_partials, (int)h, (int)s, (int)d, (int)max_step,
                        d_adj_hidden, d_features_hidden, (int)n_slices, red_in, (int)red_p, (int)red_v,
-                       project_pow2_ceil((int)red_v), red_out, a);
+                       project_pow2_ceil((int)red_v), red_out, a, hs);
     RWK_LAUNCH_CHECK();
     return RWK_OK;
+}
+
+int rwk_hidden_backward_reduce_adam(const float *adj_hidden, const float *ah, const float *z, const float *dz_partials,
+                                    int64_t n_partials, int64_t h, int64_t s, int64_t d, int64_t max_step,
+                                    float *d_adj_hidden, float *d_features_hidden, const float *red_in, int64_t red_p,
+                                    int64_t red_v, float *red_out, float *param, float *exp_avg, float *exp_avg_sq,
+                                    float *grad_out, int64_t n, int64_t off_adj, int64_t off_feat, int64_t off_red,
+                                    const float *const *rest_srcs, const int64_t *rest_sizes, int64_t n_rest,
+                                    int64_t rest_off, const float *lr, float beta1, float beta2, float eps,
+                                    float weight_decay, int64_t *step_counters, rwk_stream_t stream_) {
+    return step_tail_launch(adj_hidden, ah, z, dz_partials, n_partials, h, s, d, max_step, d_adj_hidden,
+                            d_features_hidden, red_in, red_p, red_v, red_out, param, exp_avg, exp_avg_sq, grad_out, n,
+                            off_adj, off_feat, off_red, rest_srcs, rest_sizes, n_rest, rest_off, lr, beta1, beta2, eps,
+                            weight_decay, step_counters, HeadSumArgs{}, stream_);
+}
+
+int rwk_hidden_backward_reduce_adam_head(const float *adj_hidden, const float *ah, const float *z,
+                                         const float *dz_partials, int64_t n_partials, int64_t h, int64_t s, int64_t d,
+                                         int64_t max_step, float *d_adj_hidden, float *d_features_hidden,
+                                         const float *red_in, int64_t red_p, int64_t red_v, float *red_out,
+                                         float *param, float *exp_avg, float *exp_avg_sq, float *grad_out, int64_t n,
+                                         int64_t off_adj, int64_t off_feat, int64_t off_red,
+                                         const int64_t *rest_columns, const int64_t *rest_sizes, int64_t n_rest,
+                                         int64_t rest_off, const float *lr, float beta1, float beta2, float eps,
+                                         float weight_decay, int64_t *step_counters, const float *head_partials,
+                                         int64_t n_head_partials, int64_t head_nv, const float *d_loss,
+                                         float *head_grads_out, const float *loss_partials, float *loss_out,
+                                         int64_t n_graphs, rwk_stream_t stream_) {
+    RWK_REQUIRE_PTR(head_partials);
+    RWK_REQUIRE_PTR(d_loss);
+    RWK_REQUIRE_PTR(rest_columns);
+    RWK_REQUIRE_PTR(rest_sizes);
+    if ((loss_out == nullptr) != (loss_partials == nullptr)) return RWK_E_NULL;
+    if (n_head_partials <= 0 || n_head_partials > 256 || head_nv <= 0 || head_nv > 0x7FFFFFFF || n_graphs <= 0)
+        return RWK_E_SIZE;
+    if (n_rest <= 0 || n_rest > kTailChunks) return RWK_E_UNSUPPORTED;
+    const float *srcs[kTailChunks];
+    for (int64_t k = 0; k < n_rest; ++k) {
+        if (rest_columns[k] < 0 || rest_sizes[k] < 0 || rest_columns[k] + rest_sizes[k] > head_nv) return RWK_E_SIZE;
+        srcs[k] = head_partials + rest_columns[k];
+    }
+    const HeadSumArgs hs{head_partials, (int)n_head_partials, (int)head_nv, d_loss, head_grads_out, loss_partials,
+                         loss_out, (long long)n_graphs};
+    return step_tail_launch(adj_hidden, ah, z, dz_partials, n_partials, h, s, d, max_step, d_adj_hidden,
+                            d_features_hidden, red_in, red_p, red_v, red_out, param, exp_avg, exp_avg_sq, grad_out, n,
+                            off_adj, off_feat, off_red, srcs, rest_sizes, n_rest, rest_off, lr, beta1, beta2, eps,
+                            weight_decay, step_counters, hs, stream_);
 }
 
 }  // extern "C"

@@ -30,6 +30,11 @@ MERGED_LAUNCHES = True
 #: kernel serves), and the batch statistics of the head inside the K reduction; False keeps the stand-alone
 #: launches (tests compare the two)
 FUSED_STEP_LAUNCHES = True
+#: single-process training step with the optimiser's update in the last launch (optim.StepTail): leave out the head's
+#: finishing launch as well - the batch-norm backward moves into the fused backward kernel (each lane forms the
+#: gradient elements of the graphs it walks), the head's parameter-gradient sums into the last launch; False keeps
+#: the head's own launch (tests compare the two)
+FOLD_HEAD_FINISH = True
 
 def choose_stream_len(n_nodes: int, hidden_dim: int, n_hidden: int, size_hidden: int, max_step: int,
                       backward: bool = False) -> int:
@@ -152,6 +157,11 @@ class _RWKernelLayer(torch.autograd.Function):
                 _lib.check(lib.rwk_fused_reduce(k_partials.data_ptr(), st.seg_ptr.data_ptr(),
                                                 st.counts_f32.data_ptr(), g, n_hidden, steps, stream_len, drop,
                                                 int(bool(normalize)), k.data_ptr(), stream), "rwk_fused_reduce")
+        if handoff is not None:
+            tail = handoff.get("tail")
+            handoff["fold_ok"] = bool(
+                FOLD_HEAD_FINISH and fuse_step and tail is not None and s > 1 and not ctx.needs_input_grad[0]
+                and "stats" in handoff and lib.rwk_fused_backward_bn_supported(d, n_hidden, s, steps))
         ctx.st = st
         ctx.cfg = (steps, bool(normalize), drop, projected)
         ctx.fuse_step = fuse_step
@@ -181,11 +191,22 @@ class _RWKernelLayer(torch.autograd.Function):
             dz_partials = torch.empty((n_part, steps * n_hidden * s * d), dtype=torch.float32, device=dev)
             ws_n = plan["ws"]
             ws = torch.empty(ws_n, dtype=torch.float32, device=dev) if ws_n else None
-            _lib.check(lib.rwk_fused_backward(xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm),
-                                              d_k.data_ptr(), st.counts_f32.data_ptr(), n, d, n_hidden, s, steps,
-                                              stream_len, drop, int(normalize), _lib.ptr(rng_used),
-                                              dx.data_ptr(), dz_partials.data_ptr(), _lib.ptr(ws), stream),
-                       "rwk_fused_backward")
+            fold = ctx.handoff.pop("head_fold", None) if ctx.handoff is not None else None
+            if fold is not None:
+                # the head left its finishing launch out: d_k is a placeholder, the kernel forms it (head.py)
+                _lib.check(lib.rwk_fused_backward_bn(
+                    xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm), st.counts_f32.data_ptr(), n, d,
+                    n_hidden, s, steps, stream_len, drop, int(normalize), _lib.ptr(rng_used), dx.data_ptr(),
+                    dz_partials.data_ptr(), fold["k"].data_ptr(), fold["dy"].data_ptr(), fold["mean"].data_ptr(),
+                    fold["invstd"].data_ptr(), fold["bn_w"].data_ptr(), fold["partials"].data_ptr(),
+                    fold["partials"].shape[0], fold["partials"].shape[1], fold["o_gamma"], fold["d_loss"].data_ptr(),
+                    st.n_graphs, stream), "rwk_fused_backward_bn")
+            else:
+                _lib.check(lib.rwk_fused_backward(xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm),
+                                                  d_k.data_ptr(), st.counts_f32.data_ptr(), n, d, n_hidden, s, steps,
+                                                  stream_len, drop, int(normalize), _lib.ptr(rng_used),
+                                                  dx.data_ptr(), dz_partials.data_ptr(), _lib.ptr(ws), stream),
+                           "rwk_fused_backward")
             # dZ partials: first level here (to at most 32 rows), the rest inside rwk_hidden_backward.  It is
             # independent of the SpMM chain and rides in the first SpMM's launch when there is one.
             dz, dz_rows, job = dz_partials, n_part, None
@@ -225,9 +246,12 @@ class _RWKernelLayer(torch.autograd.Function):
                     tail.launch(lib, stream, tail.head_sources(head_grads, hc, hp, hnc), _lib.ptr(adj_hidden_c),
                                 ah.data_ptr(), z.data_ptr(), dz.data_ptr(), dz_rows, n_hidden, s, d, steps,
                                 _lib.ptr(d_adj), d_feat.data_ptr(), partials.data_ptr(), blocks, d * f + d,
-                                wb.data_ptr())
-                    ctx.handoff["keep"] = head_grads          # the launch reads it asynchronously
+                                wb.data_ptr(), head_fold=fold, n_graphs=st.n_graphs,
+                                head_columns=tail.head_columns(hc, hp, hnc) if fold is not None else None)
+                    ctx.handoff["keep"] = (head_grads, fold)  # the launch reads them asynchronously
                 else:
+                    if fold is not None:
+                        raise RuntimeError("the head left its finishing launch to a step tail that did not run")
                     _lib.check(lib.rwk_hidden_backward_reduce(
                         _lib.ptr(adj_hidden_c), ah.data_ptr(), z.data_ptr(), dz.data_ptr(), dz_rows, n_hidden, s, d,
                         steps, _lib.ptr(d_adj), d_feat.data_ptr(), partials.data_ptr(), blocks, d * f + d,

@@ -242,6 +242,21 @@ class _FusedHeadLoss(torch.autograd.Function):
                 stream = _lib.current_stream(dev)
                 d_loss = d_loss.contiguous().float()
                 grads = torch.empty(lib.rwk_head_grad_size(c, p, nc), dtype=torch.float32, device=dev)
+                handoff = ctx.handoff
+                if (handoff is not None and handoff.get("fold_ok") and handoff.get("tail") is not None
+                        and ctx.needs_input_grad[0] and loss_partials is not None):
+                    # No launch here: the random-walk layer's backward (which runs next) forms d_k inside its fused
+                    # kernel and sums the parameter gradients in the step's last launch (function.py, optim.StepTail).
+                    # `grads` is filled by that launch; d_k is never read there, dy stands in for its shape.
+                    handoff["head_fold"] = {"k": kc, "dy": dy, "mean": mean, "invstd": invstd, "bn_w": bn_wc,
+                                            "partials": partials, "d_loss": d_loss, "loss_partials": loss_partials,
+                                            # detached: the loss with its grad_fn here would close a reference
+                                            # cycle (node -> hand-off -> loss -> node) and keep this step's autograd
+                                            # graph, AccumulateGrad nodes included, alive into the next step
+                                            "loss": loss.detach(), "grads": grads,
+                                            "o_gamma": nc * p + nc + p * c + p}
+                    handoff["head_grads"] = (grads, c, p, nc)
+                    return (dy, None) + _split_grads(grads, c, p, nc) + (None,) * 10
                 d_k = torch.empty((g, c), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
                 _lib.check(lib.rwk_head_train_backward(
                     kc.data_ptr(), g, c, p, nc, bn_wc.data_ptr(), mean.data_ptr(), invstd.data_ptr(), dy.data_ptr(),

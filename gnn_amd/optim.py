@@ -97,6 +97,8 @@ class StepTail:
         self.opt = opt
         self.done = False
         self.armed = False        # set by the trainer around its own forward + backward only
+        self._shape = None
+        self.head_folds = 0       # launches that also summed the head's parameter gradients (no finishing launch)
         params = opt.bucket.params
         want = [model.adj_hidden, model.features_hidden, model.fc.weight, model.fc.bias, model.bn.weight,
                 model.bn.bias, model.fc1.weight, model.fc1.bias, model.fc2.weight, model.fc2.bias]
@@ -110,7 +112,8 @@ class StepTail:
         self.rest_sizes = sizes[4:]
         lib = _lib.load()
         n_hidden = model.adj_hidden.shape[0]
-        n_counters = int(lib.rwk_step_tail_n_counters(n_hidden, self.n, self.rest_off))
+        n_counters = max(int(lib.rwk_step_tail_n_counters(n_hidden, self.n, self.rest_off)),
+                         int(lib.rwk_step_tail_n_counters_head(n_hidden, self.n, self.rest_off)))
         dev = opt.flat_param.device
         # one counter per workgroup of either launch shape, all at the optimiser's step count: the two shapes may
         # then alternate (the counters one shape does not touch are brought along by sync_counters)
@@ -135,15 +138,48 @@ class StepTail:
             raise ValueError("head gradient buffer does not match the optimiser's parameter sizes")
         return [base + f * o for o in (o_ga, o_be, o_w1, o_b1, o_w2, o_b2)]
 
+    def head_columns(self, c: int, p: int, nc: int):
+        """Columns of the head's partial rows (layout [w2 | b2 | w1 | b1 | gamma | beta]) at which the gradients of
+        bn.weight, bn.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias start."""
+        o_w2, o_b2 = 0, nc * p
+        o_w1 = o_b2 + nc
+        o_b1 = o_w1 + p * c
+        o_ga = o_b1 + p
+        o_be = o_ga + c
+        if [c, c, p * c, p, nc * p, nc] != self.rest_sizes:
+            raise ValueError("head gradient buffer does not match the optimiser's parameter sizes")
+        return [o_ga, o_be, o_w1, o_b1, o_w2, o_b2]
+
     def launch(self, lib, stream, head_srcs, adj_hidden, ah, z, dz, dz_rows, n_hidden, s, d, steps, d_adj, d_feat,
-               partials, blocks, red_v, red_out):
+               partials, blocks, red_v, red_out, head_fold=None, n_graphs=0, head_columns=None):
         import ctypes
         if red_v != self.red_v:
             raise ValueError("projection gradient width does not match fc.weight and fc.bias")
         o = self.opt
         n = len(head_srcs)
-        srcs = (ctypes.c_void_p * n)(*head_srcs)
         sizes = (ctypes.c_int64 * n)(*self.rest_sizes)
+        # the two launch shapes have different workgroup counts, each workgroup advancing its own counter: when the
+        # shape changes, the counters the previous shape did not touch are brought along first
+        shape = "head" if head_fold is not None else "plain"
+        if self._shape is not None and self._shape != shape:
+            self.sync_counters()
+        self._shape = shape
+        if head_fold is not None:
+            # the head's finishing launch was left out: its parameter gradients are summed here from its partial rows
+            hp_ = head_fold["partials"]
+            cols = (ctypes.c_int64 * n)(*head_columns)
+            _lib.check(lib.rwk_hidden_backward_reduce_adam_head(
+                adj_hidden, ah, z, dz, dz_rows, n_hidden, s, d, steps, d_adj, d_feat, partials, blocks, red_v, red_out,
+                o.flat_param.data_ptr(), o.exp_avg.data_ptr(), o.exp_avg_sq.data_ptr(), o.bucket.flat.data_ptr(),
+                self.n, self.off_adj, self.off_feat, self.off_red, cols, sizes, n, self.rest_off, o.lr.data_ptr(),
+                o.betas[0], o.betas[1], o.eps, o.weight_decay, self.counters.data_ptr(), hp_.data_ptr(), hp_.shape[0],
+                hp_.shape[1], head_fold["d_loss"].data_ptr(), head_fold["grads"].data_ptr(),
+                head_fold["loss_partials"].data_ptr(), head_fold["loss"].data_ptr(), int(n_graphs), stream),
+                "rwk_hidden_backward_reduce_adam_head")
+            self.head_folds += 1
+            self.done = True
+            return
+        srcs = (ctypes.c_void_p * n)(*head_srcs)
         _lib.check(lib.rwk_hidden_backward_reduce_adam(
             adj_hidden, ah, z, dz, dz_rows, n_hidden, s, d, steps, d_adj, d_feat, partials, blocks, red_v, red_out,
             o.flat_param.data_ptr(), o.exp_avg.data_ptr(), o.exp_avg_sq.data_ptr(), o.bucket.flat.data_ptr(), self.n,

@@ -198,6 +198,22 @@ int rwk_fused_backward(const float *x, const float *z, const int32_t *gid, const
                        int normalize, const uint64_t *rng, float *dx, float *dz_partials,
                        float *workspace, rwk_stream_t stream);
 
+/* rwk_fused_backward with the end of the head's backward pass inside (training step, hidden_dim <= 4,
+ * max_step * h <= 32; rwk_fused_backward_bn_supported says whether): instead of reading d_k, the kernel forms the
+ * gradient behind the batch-norm of model.py:68 itself, from what rwk_head_train_forward left: dy (G, L*H), the
+ * gradient at the batch-norm's output for d(loss) = 1; head_partials (n_head_partials, head_nv), whose columns
+ * [o_gamma, o_gamma + 2 L H) hold the per-workgroup sums for gamma and beta; k (G, L*H), mean, invstd, bn_w; d_loss
+ * (one float, device memory).  Same values as rwk_head_train_backward's d_k followed by rwk_fused_backward, bit for
+ * bit, with one launch less (the parameter gradients of the head are then summed by
+ * rwk_hidden_backward_reduce_adam_head). */
+int rwk_fused_backward_bn_supported(int64_t d, int64_t h, int64_t s, int64_t max_step);
+int rwk_fused_backward_bn(const float *x, const float *z, const int32_t *gid, const int32_t *perm,
+                          const float *counts_f32, int64_t n, int64_t d, int64_t h, int64_t s, int64_t max_step,
+                          int64_t stream_len, float drop_p, int normalize, const uint64_t *rng, float *dx,
+                          float *dz_partials, const float *k, const float *dy, const float *mean, const float *invstd,
+                          const float *bn_w, const float *head_partials, int64_t n_head_partials, int64_t head_nv,
+                          int64_t o_gamma, const float *d_loss, int64_t n_graphs, rwk_stream_t stream);
+
 /* Floats of `workspace` rwk_fused_backward needs (0: pass NULL).  Currently always 0: on the
  * matrix-core path the blocks of 16 hidden graphs are added into dx in place, in block order. */
 int64_t rwk_fused_backward_workspace(int64_t n, int64_t d, int64_t h, int64_t s, int64_t max_step);
@@ -426,6 +442,29 @@ int rwk_hidden_backward_reduce_adam(const float *adj_hidden, const float *ah, co
                                     const float *const *rest_srcs, const int64_t *rest_sizes, int64_t n_rest,
                                     int64_t rest_off, const float *lr, float beta1, float beta2, float eps,
                                     float weight_decay, int64_t *step_counters, rwk_stream_t stream);
+
+/* The same launch when the head's finishing launch (rwk_head_train_backward) is left out and its batch-norm part
+ * runs inside rwk_fused_backward_bn: the n_rest remaining tensors are the head's parameters, and their gradients are
+ * summed here from the per-workgroup rows head_partials (n_head_partials <= 256 rows of head_nv floats, for
+ * d(loss) = 1) - tensor k takes columns [rest_columns[k], rest_columns[k] + rest_sizes[k]) - in the order of the
+ * head's finishing kernel, times d_loss[0]: bit for bit the gradients that kernel writes.  head_grads_out (head_nv
+ * floats, may be NULL) receives them in the partial rows' layout; loss_out (may be NULL, then loss_partials too)
+ * the mean of the n_head_partials per-workgroup loss sums over n_graphs.  Eight lanes serve one element:
+ * step_counters holds rwk_step_tail_n_counters_head(h, n, rest_off) int64.  No counterpart in the reference beyond
+ * the lines the two launches it merges already cite (model.py:68-72 backward, main.py:85-87). */
+int64_t rwk_step_tail_n_counters_head(int64_t h, int64_t n, int64_t rest_off);
+int rwk_hidden_backward_reduce_adam_head(const float *adj_hidden, const float *ah, const float *z,
+                                         const float *dz_partials, int64_t n_partials, int64_t h, int64_t s, int64_t d,
+                                         int64_t max_step, float *d_adj_hidden, float *d_features_hidden,
+                                         const float *red_in, int64_t red_p, int64_t red_v, float *red_out,
+                                         float *param, float *exp_avg, float *exp_avg_sq, float *grad_out, int64_t n,
+                                         int64_t off_adj, int64_t off_feat, int64_t off_red,
+                                         const int64_t *rest_columns, const int64_t *rest_sizes, int64_t n_rest,
+                                         int64_t rest_off, const float *lr, float beta1, float beta2, float eps,
+                                         float weight_decay, int64_t *step_counters, const float *head_partials,
+                                         int64_t n_head_partials, int64_t head_nv, const float *d_loss,
+                                         float *head_grads_out, const float *loss_partials, float *loss_out,
+                                         int64_t n_graphs, rwk_stream_t stream);
 
 /* out[v] = sum_p in[p, v], rows added in a fixed order (p > 32: 32 row blocks of ceil(p/32) rows,
  * each summed by 4 interleaved slices, then the 32 block sums in index order; v <= 64 columns: one

@@ -162,6 +162,57 @@ def test_multi_step_graph_equals_single_step_replays(dev, drop):
 
 
 @pytest.mark.parametrize("drop", [0.0, 0.2])
+def test_head_finish_folded_into_the_layer_backward(dev, drop, monkeypatch):
+    """Single-process step without the head's finishing launch (function.FOLD_HEAD_FINISH): the batch-norm backward
+    inside the fused backward kernel, the head's parameter-gradient sums and the mean loss inside the step's last
+    launch - against the same step with the head's own launch: parameters, moments, flat gradient, the .grad
+    tensors, loss and step counters bit for bit, eagerly, replayed from a graph, and when the two shapes alternate."""
+    import gnn_amd.function as fn
+    c = GoldenCase("mutag_b0")
+    hp = dict(c.hp, dropout=drop)
+    folded, plain = _trainer(c, hp, dev), _trainer(c, hp, dev)
+    assert folded.tail is not None and plain.tail is not None
+
+    def step(tr, fold, graph=False):
+        monkeypatch.setattr(fn, "FOLD_HEAD_FINISH", fold)
+        tr.step_graph() if graph else tr.step_eager()
+
+    def same():
+        torch.cuda.synchronize()
+        for a, b in ((folded.opt.flat_param, plain.opt.flat_param), (folded.opt.exp_avg, plain.opt.exp_avg),
+                     (folded.opt.exp_avg_sq, plain.opt.exp_avg_sq), (folded.bucket.flat, plain.bucket.flat),
+                     (folded.model._rng_state, plain.model._rng_state)):
+            assert torch.equal(a, b)
+        for pf, pp in zip(folded.model.parameters(), plain.model.parameters()):
+            assert torch.equal(pf.grad, pp.grad)
+        assert float(folded.loss) == float(plain.loss)
+
+    for _ in range(3):
+        step(folded, True)
+        step(plain, False)
+        same()
+    assert folded.tail.head_folds == 3 and plain.tail.head_folds == 0
+    t = int(folded.opt.step_counters[0])
+    assert int(folded.opt.step_counters.min()) == t == 3
+    step(folded, False)                   # the shapes alternate: the counters follow
+    step(plain, False)
+    step(folded, True)
+    step(plain, False)
+    same()
+    monkeypatch.setattr(fn, "FOLD_HEAD_FINISH", True)
+    folded.capture()                      # 3 eager steps, then the captured one
+    monkeypatch.setattr(fn, "FOLD_HEAD_FINISH", False)
+    plain.capture()
+    n = folded.tail.head_folds
+    for _ in range(3):
+        step(folded, True, graph=True)
+        step(plain, False, graph=True)
+    same()
+    assert folded.tail.head_folds == n    # replays launch nothing from the host
+    assert int(folded.opt.step_counters.min()) == int(folded.opt.step_counters.max()) == int(plain.opt.step_counters[0])
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.2])
 def test_optimiser_update_inside_the_last_backward_launch(dev, drop):
     """Single-process step: the Adam update applied by the backward pass's last launch (optim.StepTail) against the
     same step with the stand-alone Adam launch - parameters, both moment buffers, the flat gradient and the step
