@@ -20,6 +20,8 @@ constexpr int DP = 4;
 // Waves per SIMD the backward kernel is compiled for: L*S*4 dZ accumulators + L*S*4 rows of Z must fit.
 // 4 (<= 128 VGPRs, four 256-thread workgroups per CU) up to L*S = 10, then 2, then 1.
 constexpr int bwd_waves_per_simd(int ls) { return ls <= 10 ? 3 : (ls <= 20 ? 2 : 1); }
+// instances whose backward kernel can take the head's batch-norm backward (BnFold)
+constexpr bool bn_fold_built(int lt, int st) { return lt * st <= 10; }
 // The forward kernel keeps L*S*4 rows of Z, the prefetched slot and the running sums: four workgroups per CU up to
 // L*S = 10, three up to 20 (168 VGPRs), two up to 32, else one; the keep-S instances carry S times the running
 // sums and are compiled one tier lower.
@@ -334,10 +336,13 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     // folded batch-norm backward (never with KS): the 2c column sums of the head's partial rows, requested before
     // anything else is waited for and added in the order of the head's own finishing kernel (8 lanes per column,
     // rows lane8, lane8 + 8, ..., then the eight lanes)
-    const bool fold = !KS && bn.partials != nullptr;
-    RwkFinPartials bn_pre[2];
+    // Compiled into the instances of the three-workgroups-per-CU tier only (L*S <= 10): the wider ones have no
+    // registers to spare (32 more live values in the prologue made the L*S = 20 instance spill).
+    constexpr bool kFoldBuilt = !KS && bn_fold_built(LT, ST);
+    const bool fold = kFoldBuilt && bn.partials != nullptr;
+    RwkFinPartials bn_pre[kFoldBuilt ? 2 : 1];
     const int bn_c = LT * h;
-    if (fold) {
+    if constexpr (kFoldBuilt) if (fold) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int q = it * (kBlock / 8) + (tid >> 3);
@@ -380,7 +385,7 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
         red_off = (((idx / DP) % LT) * kBlock + group0) * DP + idx % DP;      // in floats from &tile.x[0][0]
     }
     float bn_dl = 1.f;
-    if (fold) {
+    if constexpr (kFoldBuilt) if (fold) {
         bn_dl = bn.d_loss[0];
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -421,7 +426,7 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                 g_cur = g;
                 float f = scale;
                 if (normalize) f /= counts_f32[g];
-                if (fold) {
+                if (kFoldBuilt && fold) {
                     // this lane's elements of d(loss)/d(K[g]) from the head's intermediates (every load independent)
                     float e_dy[LT], e_k[LT], e_mu[LT], e_is[LT], e_w[LT];
 #pragma unroll
@@ -648,7 +653,8 @@ bool supported(int64_t d, int64_t h, int64_t s, int64_t max_step) {
 }
 
 bool bn_fold_supported(int64_t d, int64_t h, int64_t s, int64_t max_step) {
-    return supported(d, h, s, max_step) && max_step * h <= 32;     // the 2c column sums fit the kernel's 64 slots
+    // the 2c column sums fit the kernel's 64 slots, and the instance carries the code
+    return supported(d, h, s, max_step) && max_step * h <= 32 && bn_fold_built((int)max_step, (int)s);
 }
 
 bool keep_s_supported(int64_t d, int64_t h, int64_t s, int64_t max_step) {

@@ -275,3 +275,47 @@ def test_graph_replay_equals_eager_full_size_with_dropout(name, dev):
         assert torch.equal(pe, pg)
     for be, bg in zip(eager.model.buffers(), graph.model.buffers()):
         assert torch.equal(be, bg)
+
+
+def test_step_without_head_finish_launch_full_size(dev, monkeypatch):
+    """The benchmarked step (proteins1024, dropout 0.2, 1024 graphs) with the head's finishing launch folded into the
+    fused backward kernel and the step's last launch, against the same step with the head's own launch (which the
+    other tests hold against the oracle): loss, flat gradient, parameters and buffers bit for bit after four steps,
+    and a multi-step graph replay on top."""
+    import gnn_amd.function as fn
+    from gnn_amd import RW_NN
+    from gnn_amd.synth import CONFIGS, config_batch
+    from gnn_amd.trainer import Trainer
+    hp = dict(CONFIGS["proteins1024"]["hp"])
+    batch_t = config_batch("proteins1024", 1).to_torch(dev)
+
+    def trainer():
+        torch.manual_seed(0)
+        m = RW_NN(hp["input_dim"], hp["max_step"], hp["hidden_graphs"], hp["size_hidden_graphs"], hp["hidden_dim"],
+                  hp["penultimate_dim"], hp["normalize"], hp["n_classes"], hp["dropout"], dev).to(dev)
+        m.train()
+        m.seed_dropout(4321)
+        return Trainer(m, batch_t)
+
+    folded, plain = trainer(), trainer()
+    for _ in range(4):
+        monkeypatch.setattr(fn, "FOLD_HEAD_FINISH", True)
+        folded.step_eager()
+        monkeypatch.setattr(fn, "FOLD_HEAD_FINISH", False)
+        plain.step_eager()
+        torch.cuda.synchronize()
+        assert torch.equal(folded.loss, plain.loss)
+        assert torch.equal(folded.bucket.flat, plain.bucket.flat)
+    assert folded.tail.head_folds == 4 and plain.tail.head_folds == 0
+    monkeypatch.setattr(fn, "FOLD_HEAD_FINISH", True)
+    folded.capture(steps_per_graph=3)     # three more eager steps, then the captures
+    monkeypatch.setattr(fn, "FOLD_HEAD_FINISH", False)
+    for _ in range(3 + 4):
+        plain.step_eager()
+    folded.run_steps(4)                   # one replay of three steps, one single replay
+    torch.cuda.synchronize()
+    assert torch.equal(folded.loss, plain.loss)
+    for pf, pp in zip(folded.model.parameters(), plain.model.parameters()):
+        assert torch.equal(pf, pp)
+    for bf, bp in zip(folded.model.buffers(), plain.model.buffers()):
+        assert torch.equal(bf, bp)
