@@ -111,6 +111,7 @@ __device__ inline double pow_int(double b, long long t) {
 
 __device__ inline void adam_element(const AdamTailArgs &a, const float *corr, long long i, float g) {
     if (a.grad_out != nullptr) a.grad_out[i] = g;
+    if (a.param == nullptr) return;      // gradient only: the update follows the data-parallel all-reduce
     const float p = a.param[i];
     if (a.weight_decay != 0.f) g = fmaf(a.weight_decay, p, g);
     const float m = fmaf(a.beta1, a.exp_avg[i], (1.f - a.beta1) * g);
@@ -142,7 +143,7 @@ hidden_backward_reduce_adam_kernel(const float *__restrict__ adj_hidden, const f
                                    HeadSumArgs hs) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float corr[2];
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && a.param != nullptr) {
         const long long t = a.counters[blockIdx.x] + 1;
         a.counters[blockIdx.x] = t;
         corr[0] = (float)(1.0 - pow_int((double)a.beta1, t));
@@ -290,11 +291,14 @@ static int step_tail_launch(const float *adj_hidden, const float *ah, const floa
     RWK_REQUIRE_PTR(d_features_hidden);
     RWK_REQUIRE_PTR(red_in);
     RWK_REQUIRE_PTR(red_out);
-    RWK_REQUIRE_PTR(param);
-    RWK_REQUIRE_PTR(exp_avg);
-    RWK_REQUIRE_PTR(exp_avg_sq);
-    RWK_REQUIRE_PTR(lr);
-    RWK_REQUIRE_PTR(step_counters);
+    if (param != nullptr) {
+        RWK_REQUIRE_PTR(exp_avg);
+        RWK_REQUIRE_PTR(exp_avg_sq);
+        RWK_REQUIRE_PTR(lr);
+        RWK_REQUIRE_PTR(step_counters);
+    } else {
+        RWK_REQUIRE_PTR(grad_out);       // gradient-only launch: the flat gradient is all it leaves
+    }
     if (h <= 0 || s <= 1 || d <= 0 || max_step <= 1 || n_partials <= 0 || h > 65535) return RWK_E_SIZE;
     if (red_p <= 0 || red_p > (1 << 20) || red_v <= 0) return RWK_E_SIZE;
     if (red_v > 64) return RWK_E_UNSUPPORTED;

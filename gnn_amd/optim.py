@@ -93,8 +93,11 @@ class StepTail:
     Requires the flat buffer to start with ``adj_hidden, features_hidden, fc.weight, fc.bias`` (``RW_NN``'s
     parameter order) followed by the head's six tensors."""
 
-    def __init__(self, model, opt: FlatAdam):
+    def __init__(self, model, opt: FlatAdam, update: bool = True):
         self.opt = opt
+        # update=False (data-parallel step): the launch only completes the flat gradient bucket - no gather launch,
+        # no finishing launch of the head - and the all-reduce and the stand-alone Adam launch follow
+        self.update = bool(update)
         self.done = False
         self.armed = False        # set by the trainer around its own forward + backward only
         self._shape = None
@@ -117,13 +120,17 @@ class StepTail:
         dev = opt.flat_param.device
         # one counter per workgroup of either launch shape, all at the optimiser's step count: the two shapes may
         # then alternate (the counters one shape does not touch are brought along by sync_counters)
+        if not self.update:
+            self.counters = None          # the stand-alone Adam launch keeps its own
+            return
         self.counters = torch.zeros(max(n_counters, opt.step_counters.numel()), dtype=torch.int64, device=dev)
         self.counters.copy_(opt.step_counters[:1].expand_as(self.counters))
         opt.step_counters = self.counters
 
     def sync_counters(self):
         """After an update by the stand-alone Adam launch (which advances only its own workgroups' counters)."""
-        self.counters.copy_(self.counters[:1].expand_as(self.counters))
+        if self.counters is not None:
+            self.counters.copy_(self.counters[:1].expand_as(self.counters))
 
     def head_sources(self, head_grads: torch.Tensor, c: int, p: int, nc: int):
         """Device addresses of the gradients of bn.weight, bn.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias inside
@@ -160,8 +167,9 @@ class StepTail:
         sizes = (ctypes.c_int64 * n)(*self.rest_sizes)
         # the two launch shapes have different workgroup counts, each workgroup advancing its own counter: when the
         # shape changes, the counters the previous shape did not touch are brought along first
+        upd = (lambda t: t.data_ptr()) if self.update else (lambda t: None)
         shape = "head" if head_fold is not None else "plain"
-        if self._shape is not None and self._shape != shape:
+        if self.update and self._shape is not None and self._shape != shape:
             self.sync_counters()
         self._shape = shape
         if head_fold is not None:
@@ -170,9 +178,9 @@ class StepTail:
             cols = (ctypes.c_int64 * n)(*head_columns)
             _lib.check(lib.rwk_hidden_backward_reduce_adam_head(
                 adj_hidden, ah, z, dz, dz_rows, n_hidden, s, d, steps, d_adj, d_feat, partials, blocks, red_v, red_out,
-                o.flat_param.data_ptr(), o.exp_avg.data_ptr(), o.exp_avg_sq.data_ptr(), o.bucket.flat.data_ptr(),
-                self.n, self.off_adj, self.off_feat, self.off_red, cols, sizes, n, self.rest_off, o.lr.data_ptr(),
-                o.betas[0], o.betas[1], o.eps, o.weight_decay, self.counters.data_ptr(), hp_.data_ptr(), hp_.shape[0],
+                upd(o.flat_param), upd(o.exp_avg), upd(o.exp_avg_sq), o.bucket.flat.data_ptr(),
+                self.n, self.off_adj, self.off_feat, self.off_red, cols, sizes, n, self.rest_off, upd(o.lr),
+                o.betas[0], o.betas[1], o.eps, o.weight_decay, upd(self.counters), hp_.data_ptr(), hp_.shape[0],
                 hp_.shape[1], head_fold["d_loss"].data_ptr(), head_fold["grads"].data_ptr(),
                 head_fold["loss_partials"].data_ptr(), head_fold["loss"].data_ptr(), int(n_graphs), stream),
                 "rwk_hidden_backward_reduce_adam_head")
@@ -182,7 +190,7 @@ class StepTail:
         srcs = (ctypes.c_void_p * n)(*head_srcs)
         _lib.check(lib.rwk_hidden_backward_reduce_adam(
             adj_hidden, ah, z, dz, dz_rows, n_hidden, s, d, steps, d_adj, d_feat, partials, blocks, red_v, red_out,
-            o.flat_param.data_ptr(), o.exp_avg.data_ptr(), o.exp_avg_sq.data_ptr(), o.bucket.flat.data_ptr(), self.n,
-            self.off_adj, self.off_feat, self.off_red, srcs, sizes, n, self.rest_off, o.lr.data_ptr(), o.betas[0],
-            o.betas[1], o.eps, o.weight_decay, self.counters.data_ptr(), stream), "rwk_hidden_backward_reduce_adam")
+            upd(o.flat_param), upd(o.exp_avg), upd(o.exp_avg_sq), o.bucket.flat.data_ptr(), self.n,
+            self.off_adj, self.off_feat, self.off_red, srcs, sizes, n, self.rest_off, upd(o.lr), o.betas[0],
+            o.betas[1], o.eps, o.weight_decay, upd(self.counters), stream), "rwk_hidden_backward_reduce_adam")
         self.done = True

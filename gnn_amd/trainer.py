@@ -54,10 +54,12 @@ class Trainer:
         self.fused_gather = world == 1 and optimizer == "flat"
         # ... and for RW_NN the Adam update itself rides in the backward pass's last launch (optim.StepTail), whenever
         # the step takes the fused path (narrow inputs, hidden_dim 4, at least two steps, fused head with the loss)
+        # Data parallel: the same launch without the update - it completes the flat gradient bucket (no gather launch,
+        # no finishing launch of the head); the all-reduce and the stand-alone Adam launch follow.
         self.tail = None
-        if merge_tail and self.fused_gather and self.loss_in_head:
+        if merge_tail and optimizer == "flat" and self.loss_in_head:
             try:
-                self.tail = StepTail(model, self.opt)
+                self.tail = StepTail(model, self.opt, update=world == 1)
                 model._step_tail = self.tail
             except (ValueError, AttributeError):
                 self.tail = None
@@ -96,7 +98,9 @@ class Trainer:
         finally:
             if self.tail is not None:
                 self.tail.armed = False
-        if not self.fused_gather:
+        if self.tail is not None and not self.tail.update and self.tail.done:
+            self.tail.done = False       # the backward pass's last launch left the flat gradient in the bucket
+        elif not self.fused_gather:
             self.bucket.gather()         # per-parameter gradients -> the flat bucket, one launch
 
     def step_eager(self):

@@ -432,7 +432,10 @@ int rwk_hidden_backward_reduce(const float *adj_hidden, const float *ah, const f
  * param / exp_avg / exp_avg_sq / grad_out (may be NULL: the flat gradient is not kept) are flat buffers of n floats
  * holding adj_hidden at off_adj, features_hidden at off_feat, the column sums at off_red - together exactly
  * [0, rest_off) - and the remaining tensors back to back in [rest_off, n).  step_counters:
- * rwk_step_tail_n_counters(h, n, rest_off) int64 at one common step count (each workgroup advances its own). */
+ * rwk_step_tail_n_counters(h, n, rest_off) int64 at one common step count (each workgroup advances its own).
+ * param == NULL: no update (exp_avg, exp_avg_sq, lr, step_counters are not touched and may be NULL); the launch then
+ * only completes the flat gradient in grad_out (required) - the data-parallel step, whose all-reduce and
+ * rwk_adam_step follow. */
 int64_t rwk_step_tail_n_counters(int64_t h, int64_t n, int64_t rest_off);
 int rwk_hidden_backward_reduce_adam(const float *adj_hidden, const float *ah, const float *z, const float *dz_partials,
                                     int64_t n_partials, int64_t h, int64_t s, int64_t d, int64_t max_step,

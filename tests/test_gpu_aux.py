@@ -213,6 +213,37 @@ def test_head_finish_folded_into_the_layer_backward(dev, drop, monkeypatch):
 
 
 @pytest.mark.parametrize("drop", [0.0, 0.2])
+def test_data_parallel_step_shape_without_gather_and_head_finish_launches(dev, drop):
+    """The step in the shape of a 2-rank run (no process group: the all-reduce slot is a no-op): the backward pass's
+    last launch completes the flat gradient bucket - no gather launch, no finishing launch of the head, no update -
+    against the same shape with those launches: bucket, parameters, moments and loss bit for bit, eager and replayed."""
+    c = GoldenCase("mutag_b0")
+    hp = dict(c.hp, dropout=drop)
+    merged, plain = _trainer(c, hp, dev, world=2), _trainer(c, hp, dev, world=2, merge_tail=False)
+    assert merged.tail is not None and not merged.tail.update and plain.tail is None
+
+    def same():
+        torch.cuda.synchronize()
+        for a, b in ((merged.opt.flat_param, plain.opt.flat_param), (merged.opt.exp_avg, plain.opt.exp_avg),
+                     (merged.opt.exp_avg_sq, plain.opt.exp_avg_sq), (merged.bucket.flat, plain.bucket.flat)):
+            assert torch.equal(a, b)
+        assert float(merged.loss) == float(plain.loss)
+
+    for _ in range(3):
+        merged.step_eager()
+        plain.step_eager()
+        same()
+    assert merged.tail.head_folds == 3
+    merged.capture()
+    plain.capture()
+    assert merged.g_opt is not None
+    for _ in range(3):
+        merged.step_graph()
+        plain.step_graph()
+    same()
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.2])
 def test_optimiser_update_inside_the_last_backward_launch(dev, drop):
     """Single-process step: the Adam update applied by the backward pass's last launch (optim.StepTail) against the
     same step with the stand-alone Adam launch - parameters, both moment buffers, the flat gradient and the step
