@@ -18,7 +18,7 @@ from .dp import FlatGradBucket
 from .losses import cross_entropy
 from .optim import FlatAdam, StepTail
 
-__all__ = ["Trainer"]
+__all__ = ["Trainer", "EpochTrainer"]
 
 
 class Trainer:
@@ -266,3 +266,60 @@ class Trainer:
             out["all_reduce_ms"] = med([e[1].elapsed_time(e[2]) for e in ev])
             out["optimizer_graph_ms"] = med([e[2].elapsed_time(e[3]) for e in ev])
         return out
+
+
+class EpochTrainer(Trainer):
+    """The reference's epoch over its training batches (``rwgnn2/main.py:103-106``: ``for i in range(n_train_batches):
+    train(epoch, adj_train[i], features_train[i], graph_indicator_train[i], y_train[i])``) as ONE replayed graph.
+
+    ``batches``: the lists ``generate_batches`` returns, zipped - ``[(adj, features, graph_indicator, y), ...]``, all
+    resident on the device (they are reused every epoch, ``main.py:70-72``).  ``epoch_eager()`` runs the steps one
+    after the other; ``capture_epoch()`` records them once (after one eager epoch as warm-up, which trains like any
+    other) and ``run_epoch()`` replays them: one replay start per epoch instead of one per step, no host work per
+    batch.  ``epoch_losses`` holds one loss tensor per batch (read them after the epoch, as ``main.py:87`` does with
+    ``loss.item()``); a learning-rate schedule (``main.py:80,108``) sets the rate between replays
+    (``trainer.opt.set_lr``, the rate lives on the device).  Single process; data-parallel runs use ``Trainer``."""
+
+    def __init__(self, model, batches, **kw):
+        batches = [tuple(b) for b in batches]
+        if not batches:
+            raise ValueError("no batches")
+        if kw.get("world", 1) != 1:
+            raise ValueError("EpochTrainer is single-process; use Trainer for data-parallel steps")
+        super().__init__(model, batches[0], **kw)
+        self.batches = batches
+        self.epoch_losses = []
+        self.g_epoch = None
+
+    def set_batch(self, batch_t):
+        self.adj, self.feats, self.gi, self.y = batch_t
+
+    def _epoch(self):
+        losses = []
+        for b in self.batches:
+            self.set_batch(b)
+            self.fwd_bwd()
+            self._opt_step()
+            losses.append(self.loss.detach())
+        return losses
+
+    def epoch_eager(self):
+        self.epoch_losses = self._epoch()
+        return self.epoch_losses
+
+    def capture_epoch(self):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.epoch_eager()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.loss = None                  # drop the warm-up's autograd graph (see Trainer.capture)
+        self.g_epoch = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_epoch, capture_error_mode=self.capture_error_mode):
+            self.epoch_losses = self._epoch()
+        self.loss = self.epoch_losses[-1]
+
+    def run_epoch(self):
+        self.g_epoch.replay()
+        return self.epoch_losses

@@ -106,3 +106,41 @@ def test_batches_feed_the_model():
     F.cross_entropy(out, y_l[0]).backward()
     assert out.shape == (64, 2) and torch.isfinite(out).all()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+@pytest.mark.gpu
+def test_epoch_graph_trains_like_the_step_loop():
+    """The reference's epoch over its MUTAG training batches (main.py:103-106) replayed as one HIP graph
+    (gnn_amd.trainer.EpochTrainer) against the same steps launched one by one: per-batch losses, parameters, moments
+    and running statistics bit for bit after three epochs, dropout on."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gnn_amd import RW_NN
+    from gnn_amd.data import generate_batches, load_data
+    from gnn_amd.trainer import EpochTrainer
+    dev = torch.device("cuda:0")
+    adj, features, y = load_data("MUTAG", False, root=ROOT)
+    y = np.unique(y, return_inverse=True)[1]
+    batches = list(zip(*generate_batches(adj, features, y, 64, dev)))
+    assert len(batches) == 3
+
+    def trainer():
+        torch.manual_seed(0)
+        m = RW_NN(1, 2, 16, 5, 4, 32, False, 2, 0.2, dev).to(dev).train()
+        m.seed_dropout(99)
+        return EpochTrainer(m, batches)
+
+    eager, graph = trainer(), trainer()
+    graph.capture_epoch()                 # one eager epoch, then the capture
+    eager.epoch_eager()
+    for _ in range(3):
+        le = [float(v) for v in eager.epoch_eager()]
+        lg = [float(v) for v in graph.run_epoch()]
+        assert le == lg and all(np.isfinite(le))
+    graph.opt.set_lr(5e-3)                # a schedule changes the rate between replays
+    eager.opt.set_lr(5e-3)
+    assert [float(v) for v in eager.epoch_eager()] == [float(v) for v in graph.run_epoch()]
+    for a, b in ((eager.opt.flat_param, graph.opt.flat_param), (eager.opt.exp_avg, graph.opt.exp_avg),
+                 (eager.opt.exp_avg_sq, graph.opt.exp_avg_sq), (eager.model.bn.running_mean, graph.model.bn.running_mean),
+                 (eager.model.bn.running_var, graph.model.bn.running_var), (eager.model._rng_state, graph.model._rng_state)):
+        assert torch.equal(a, b)
