@@ -213,6 +213,19 @@ __device__ inline void put_slot(Tile<LT> &tile, const Slot<LT> &sl, bool has_str
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// Forward kernel at two steps: the rows of step 0 and step 1 of a slot interleaved, tile.x[0][t] = (x0[0], x1[0],
+// x0[1], x1[1]) and tile.x[1][t] = (x0[2], x1[2], x0[3], x1[3]), so that a 16-byte LDS read yields two (step 0,
+// step 1) operand pairs of the packed multiply-adds as they stand (row-major rows cost a register move per pair).
+__device__ inline void put_slot_pairs(Tile<2> &tile, const Slot<2> &sl, bool has_stream) {
+    const int t = threadIdx.x;
+    tile.node[t] = sl.valid ? sl.node : -1;
+    tile.gid[t] = has_stream ? sl.gid : -1;
+    tile.x[0][t] = sl.valid ? make_float4(sl.x[0][0], sl.x[1][0], sl.x[0][1], sl.x[1][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    tile.x[1][t] = sl.valid ? make_float4(sl.x[0][2], sl.x[1][2], sl.x[0][3], sl.x[1][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+typedef float rwk_f2 __attribute__((ext_vector_type(2)));
+
 // HPT: lanes per stream as a compile-time constant (0 = use the run-time value hp_arg)
 // KS (keep S): the sums over the hidden nodes are not taken; slot layout [(i * h + lane) * ST + s], L*H*ST floats
 // per slot, i.e. one feature per (step, hidden graph, hidden node) - the output of rwgnn/rwgnn_pyg.py:138-149.
@@ -257,7 +270,17 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
             for (int q = 0; q < SK; ++q) dst[(size_t)i * h * SK + q] = acc[i][q];
     };
 
-    put_slot<LT>(tiles[0], slot, has_stream);
+    constexpr bool kPairs = LT == 2 && !KS;         // (step 0, step 1) operand pairs, see put_slot_pairs
+    rwk_f2 zp[kPairs ? ST : 1][DP];
+    if constexpr (kPairs) {
+#pragma unroll
+        for (int ss = 0; ss < ST; ++ss)
+#pragma unroll
+            for (int k = 0; k < DP; ++k) zp[ss][k] = rwk_f2{zr[0][ss][k], zr[1][ss][k]};
+        put_slot_pairs(tiles[0], slot, has_stream);
+    } else {
+        put_slot<LT>(tiles[0], slot, has_stream);
+    }
     __syncthreads();
     ProgressPriority priority(prio, stream_len);
     int buf = 0;
@@ -278,14 +301,37 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
                     for (int q = 0; q < SK; ++q) acc[i][q] = 0.f;
                 g_cur = g;
             }
+            Keep<NC> keep;
+            if (DROP) keep.draw(cfg, (uint32_t)node, (uint32_t)lane_h);
+            if constexpr (kPairs) {
+                // the same multiplications and additions in the same order as the general form below, two steps at a
+                // time: (zx, t) = sum_k (Z0[ss][k], Z1[ss][k]) * (x0[k], x1[k]), products (zx * zx, zx * t)
+                const float4 va = tile.x[0][group0 + j], vb = tile.x[1][group0 + j];
+                const rwk_f2 xp[DP] = {rwk_f2{va.x, va.y}, rwk_f2{va.z, va.w}, rwk_f2{vb.x, vb.y}, rwk_f2{vb.z, vb.w}};
+                rwk_f2 node2 = rwk_f2{0.f, 0.f};
+#pragma unroll
+                for (int ss = 0; ss < ST; ++ss) {
+                    rwk_f2 zt = zp[ss][0] * xp[0];
+                    zt = __builtin_elementwise_fma(zp[ss][1], xp[1], zt);
+                    zt = __builtin_elementwise_fma(zp[ss][2], xp[2], zt);
+                    zt = __builtin_elementwise_fma(zp[ss][3], xp[3], zt);
+                    rwk_f2 prod = zt * rwk_f2{zt.x, zt.x};
+                    if (DROP) {
+                        prod.x = keep.at(ss * LT) ? prod.x : 0.f;
+                        prod.y = keep.at(ss * LT + 1) ? prod.y : 0.f;
+                    }
+                    node2 += prod;
+                }
+                acc[0][0] += node2.x;
+                acc[1][0] += node2.y;
+                continue;
+            }
             float xr[LT][DP];
 #pragma unroll
             for (int i = 0; i < LT; ++i) {
                 const float4 v = tile.x[i][group0 + j];
                 xr[i][0] = v.x; xr[i][1] = v.y; xr[i][2] = v.z; xr[i][3] = v.w;
             }
-            Keep<NC> keep;
-            if (DROP) keep.draw(cfg, (uint32_t)node, (uint32_t)lane_h);
             float node_acc[LT][SK];
 #pragma unroll
             for (int i = 0; i < LT; ++i)
@@ -308,7 +354,9 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
                 for (int q = 0; q < SK; ++q) acc[i][q] += node_acc[i][q];
         }
         if (more) {
-            put_slot<LT>(tiles[buf ^ 1], slot, has_stream);     // its readers all passed the previous barrier
+            // its readers all passed the previous barrier
+            if constexpr (kPairs) put_slot_pairs(tiles[buf ^ 1], slot, has_stream);
+            else put_slot<LT>(tiles[buf ^ 1], slot, has_stream);
             __syncthreads();
         }
     }
