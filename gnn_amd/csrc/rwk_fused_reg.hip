@@ -418,6 +418,20 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     float dz[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) dz[v] = 0.f;
+    // two steps: the arithmetic runs on (step 0, step 1) pairs, one packed instruction for two of the scalar ones
+    // (same operations on the same operands: same bits); dz2[ss][k] = (dZ_0[ss][k], dZ_1[ss][k]) is unpacked into
+    // dz[] after the loop
+    constexpr bool kPairs = LT == 2 && !KS;
+    rwk_f2 zp[kPairs ? ST : 1][DP], dz2[kPairs ? ST : 1][DP];
+    if constexpr (kPairs) {
+#pragma unroll
+        for (int ss = 0; ss < ST; ++ss)
+#pragma unroll
+            for (int k = 0; k < DP; ++k) {
+                zp[ss][k] = rwk_f2{zr[0][ss][k], zr[1][ss][k]};
+                dz2[ss][k] = rwk_f2{0.f, 0.f};
+            }
+    }
     constexpr int SK = KS ? ST : 1;
     float dp_cur[LT][SK];
 #pragma unroll
@@ -503,7 +517,41 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
             }
             // no validity branch: a slot past the end of the stream has x = 0, so zx = t = 0 and every
             // product below is zero
-            {
+            if constexpr (kPairs) {
+                Keep<NC> keep;
+                if (DROP) keep.draw(cfg, (uint32_t)node, (uint32_t)lane_h);
+                rwk_f2 xp[DP], dx2[DP];
+#pragma unroll
+                for (int k = 0; k < DP; ++k) {
+                    xp[k] = rwk_f2{xr[0][k], xr[1][k]};
+                    dx2[k] = rwk_f2{0.f, 0.f};
+                }
+#pragma unroll
+                for (int ss = 0; ss < ST; ++ss) {
+                    rwk_f2 zt = zp[ss][0] * xp[0];                                  // (zx, t)
+                    zt = __builtin_elementwise_fma(zp[ss][1], xp[1], zt);
+                    zt = __builtin_elementwise_fma(zp[ss][2], xp[2], zt);
+                    zt = __builtin_elementwise_fma(zp[ss][3], xp[3], zt);
+                    float w0 = dp_cur[0][0], w1 = dp_cur[1][0];
+                    if (DROP) {
+                        w0 = keep.at(ss * LT) ? w0 : 0.f;
+                        w1 = keep.at(ss * LT + 1) ? w1 : 0.f;
+                    }
+                    float dzx = 2.f * w0 * zt.x;          // step 0 contributes keep * zx^2
+                    dzx = fmaf(w1, zt.y, dzx);
+                    const rwk_f2 cf = rwk_f2{dzx, w1 * zt.x};                       // (d zx, d t)
+#pragma unroll
+                    for (int k = 0; k < DP; ++k) {
+                        dx2[k] = __builtin_elementwise_fma(cf, zp[ss][k], dx2[k]);
+                        dz2[ss][k] = __builtin_elementwise_fma(cf, xp[k], dz2[ss][k]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < DP; ++k) {
+                    dxr[0][k] = dx2[k].x;
+                    dxr[1][k] = dx2[k].y;
+                }
+            } else {
                 Keep<NC> keep;
                 if (DROP) keep.draw(cfg, (uint32_t)node, (uint32_t)lane_h);
 #pragma unroll
@@ -577,6 +625,15 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     }
 
     RWK_STAMP_AT(3);
+    if constexpr (kPairs) {
+#pragma unroll
+        for (int ss = 0; ss < ST; ++ss)
+#pragma unroll
+            for (int k = 0; k < DP; ++k) {
+                dz[ss * DP + k] = dz2[ss][k].x;
+                dz[(ST + ss) * DP + k] = dz2[ss][k].y;
+            }
+    }
     // per-workgroup partial of dZ: threads that own the same hidden graph are added in thread order
     const int spb = kBlock / hp;
     float *out = dz_partials + (size_t)blockIdx.x * LT * h * ST * d;
