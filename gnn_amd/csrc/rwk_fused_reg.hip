@@ -422,6 +422,9 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     // (same operations on the same operands: same bits); dz2[ss][k] = (dZ_0[ss][k], dZ_1[ss][k]) is unpacked into
     // dz[] after the loop
     constexpr bool kPairs = LT == 2 && !KS;
+    // ... and with sixteen lanes per stream the tile holds the rows interleaved (put_slot_pairs): the operand pairs
+    // come out of the 16-byte LDS reads as they stand, and the dX totals are parked in the same interleaved places
+    constexpr bool kPairTile = kPairs && HPT == 16;
     rwk_f2 zp[kPairs ? ST : 1][DP], dz2[kPairs ? ST : 1][DP];
     if constexpr (kPairs) {
 #pragma unroll
@@ -445,6 +448,8 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     if (HPT == 16 && (LT == 2 || LT == 4)) {
         const int idx = rwk_halving_index<(LT == 4 ? 16 : 8)>(lane_h);
         red_off = (((idx / DP) % LT) * kBlock + group0) * DP + idx % DP;      // in floats from &tile.x[0][0]
+        // interleaved rows (put_slot_pairs): value (i, k) is float (k % 2) * 2 + i of tile.x[k / 2][slot]
+        if (kPairTile) red_off = (((idx % DP) / 2) * kBlock + group0) * DP + ((idx % DP) % 2) * 2 + (idx / DP) % LT;
     }
     float bn_dl = 1.f;
     if constexpr (kFoldBuilt) if (fold) {
@@ -458,7 +463,8 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
             if ((tid & 7) == 0 && q < 2 * bn_c) s_bn[q < bn_c ? q : 32 + (q - bn_c)] = acc * bn_dl;
         }
     }
-    put_slot<LT>(tiles[0], slot, has_stream);
+    if constexpr (kPairTile) put_slot_pairs(tiles[0], slot, has_stream);
+    else put_slot<LT>(tiles[0], slot, has_stream);
     __syncthreads();
     ProgressPriority priority(prio, stream_len);
     int buf = 0;
@@ -480,7 +486,11 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
 #pragma unroll
             for (int i = 0; i < LT; ++i) {
                 const float4 v = tile.x[i][group0 + j];
-                xr[i][0] = v.x; xr[i][1] = v.y; xr[i][2] = v.z; xr[i][3] = v.w;
+                if constexpr (kPairTile) {      // v = (x0[2i], x1[2i], x0[2i+1], x1[2i+1])
+                    xr[0][2 * i] = v.x; xr[1 % LT][2 * i] = v.y; xr[0][2 * i + 1] = v.z; xr[1 % LT][2 * i + 1] = v.w;
+                } else {
+                    xr[i][0] = v.x; xr[i][1] = v.y; xr[i][2] = v.z; xr[i][3] = v.w;
+                }
 #pragma unroll
                 for (int k = 0; k < DP; ++k) dxr[i][k] = 0.f;
             }
@@ -606,7 +616,11 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
         if (my_node >= 0) {                               // coalesced: hp lanes store hp consecutive rows
 #pragma unroll
             for (int i = 0; i < LT; ++i) {
-                const float4 mv = tile.x[i][tid];         // written by a lane of this wavefront
+                float4 mv = tile.x[i][tid];               // written by a lane of this wavefront
+                if constexpr (kPairTile) {                // de-interleave: row i = float i of every pair
+                    const float4 ma = tile.x[0][tid], mb = tile.x[1 % LT][tid];
+                    mv = i == 0 ? make_float4(ma.x, ma.z, mb.x, mb.z) : make_float4(ma.y, ma.w, mb.y, mb.w);
+                }
                 const float mine_i[DP] = {mv.x, mv.y, mv.z, mv.w};
                 float *row = dx + i * step_stride + (size_t)my_node * d;
                 if (d == DP) {
@@ -619,7 +633,9 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
             }
         }
         if (more) {
-            put_slot<LT>(tiles[buf ^ 1], slot, has_stream);     // its readers all passed the previous barrier
+            // its readers all passed the previous barrier
+            if constexpr (kPairTile) put_slot_pairs(tiles[buf ^ 1], slot, has_stream);
+            else put_slot<LT>(tiles[buf ^ 1], slot, has_stream);
             __syncthreads();
         }
     }
