@@ -213,15 +213,22 @@ __device__ inline void put_slot(Tile<LT> &tile, const Slot<LT> &sl, bool has_str
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// Forward kernel at two steps: the rows of step 0 and step 1 of a slot interleaved, tile.x[0][t] = (x0[0], x1[0],
-// x0[1], x1[1]) and tile.x[1][t] = (x0[2], x1[2], x0[3], x1[3]), so that a 16-byte LDS read yields two (step 0,
-// step 1) operand pairs of the packed multiply-adds as they stand (row-major rows cost a register move per pair).
-__device__ inline void put_slot_pairs(Tile<2> &tile, const Slot<2> &sl, bool has_stream) {
+// An even number of steps: the rows of steps 2p and 2p+1 of a slot interleaved, tile.x[2p][t] = (x_2p[0], x_2p+1[0],
+// x_2p[1], x_2p+1[1]) and tile.x[2p + 1][t] = (x_2p[2], x_2p+1[2], x_2p[3], x_2p+1[3]), so that a 16-byte LDS read yields
+// two (step 2p, step 2p+1) operand pairs of the packed multiply-adds as they stand (row-major rows cost a register move
+// per pair).
+template <int LT>
+__device__ inline void put_slot_pairs(Tile<LT> &tile, const Slot<LT> &sl, bool has_stream) {
+    static_assert(LT % 2 == 0, "pairs of steps");
     const int t = threadIdx.x;
     tile.node[t] = sl.valid ? sl.node : -1;
     tile.gid[t] = has_stream ? sl.gid : -1;
-    tile.x[0][t] = sl.valid ? make_float4(sl.x[0][0], sl.x[1][0], sl.x[0][1], sl.x[1][1]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    tile.x[1][t] = sl.valid ? make_float4(sl.x[0][2], sl.x[1][2], sl.x[0][3], sl.x[1][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int p = 0; p < LT / 2; ++p) {
+        tile.x[2 * p][t] = sl.valid ? make_float4(sl.x[2 * p][0], sl.x[2 * p + 1][0], sl.x[2 * p][1], sl.x[2 * p + 1][1]) : zero;
+        tile.x[2 * p + 1][t] = sl.valid ? make_float4(sl.x[2 * p][2], sl.x[2 * p + 1][2], sl.x[2 * p][3], sl.x[2 * p + 1][3]) : zero;
+    }
 }
 
 typedef float rwk_f2 __attribute__((ext_vector_type(2)));
@@ -270,14 +277,17 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
             for (int q = 0; q < SK; ++q) dst[(size_t)i * h * SK + q] = acc[i][q];
     };
 
-    constexpr bool kPairs = LT == 2 && !KS;         // (step 0, step 1) operand pairs, see put_slot_pairs
-    rwk_f2 zp[kPairs ? ST : 1][DP];
+    constexpr bool kPairs = LT % 2 == 0 && !KS;     // (step 2p, step 2p+1) operand pairs, see put_slot_pairs
+    constexpr int NP = kPairs ? LT / 2 : 1;
+    rwk_f2 zp[NP][kPairs ? ST : 1][DP];
     if constexpr (kPairs) {
 #pragma unroll
-        for (int ss = 0; ss < ST; ++ss)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
-            for (int k = 0; k < DP; ++k) zp[ss][k] = rwk_f2{zr[0][ss][k], zr[1][ss][k]};
-        put_slot_pairs(tiles[0], slot, has_stream);
+            for (int ss = 0; ss < ST; ++ss)
+#pragma unroll
+                for (int k = 0; k < DP; ++k) zp[p][ss][k] = rwk_f2{zr[2 * p][ss][k], zr[2 * p + 1][ss][k]};
+        put_slot_pairs<LT>(tiles[0], slot, has_stream);
     } else {
         put_slot<LT>(tiles[0], slot, has_stream);
     }
@@ -305,25 +315,41 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
             if (DROP) keep.draw(cfg, (uint32_t)node, (uint32_t)lane_h);
             if constexpr (kPairs) {
                 // the same multiplications and additions in the same order as the general form below, two steps at a
-                // time: (zx, t) = sum_k (Z0[ss][k], Z1[ss][k]) * (x0[k], x1[k]), products (zx * zx, zx * t)
-                const float4 va = tile.x[0][group0 + j], vb = tile.x[1][group0 + j];
-                const rwk_f2 xp[DP] = {rwk_f2{va.x, va.y}, rwk_f2{va.z, va.w}, rwk_f2{vb.x, vb.y}, rwk_f2{vb.z, vb.w}};
-                rwk_f2 node2 = rwk_f2{0.f, 0.f};
+                // time: (zx, t_1) = sum_k (Z_0[ss][k], Z_1[ss][k]) * (x_0[k], x_1[k]), products (zx * zx, zx * t_1), ...
+                rwk_f2 xp[NP][DP], node2[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const float4 va = tile.x[2 * p][group0 + j], vb = tile.x[2 * p + 1][group0 + j];
+                    xp[p][0] = rwk_f2{va.x, va.y}; xp[p][1] = rwk_f2{va.z, va.w};
+                    xp[p][2] = rwk_f2{vb.x, vb.y}; xp[p][3] = rwk_f2{vb.z, vb.w};
+                    node2[p] = rwk_f2{0.f, 0.f};
+                }
 #pragma unroll
                 for (int ss = 0; ss < ST; ++ss) {
-                    rwk_f2 zt = zp[ss][0] * xp[0];
-                    zt = __builtin_elementwise_fma(zp[ss][1], xp[1], zt);
-                    zt = __builtin_elementwise_fma(zp[ss][2], xp[2], zt);
-                    zt = __builtin_elementwise_fma(zp[ss][3], xp[3], zt);
-                    rwk_f2 prod = zt * rwk_f2{zt.x, zt.x};
-                    if (DROP) {
-                        prod.x = keep.at(ss * LT) ? prod.x : 0.f;
-                        prod.y = keep.at(ss * LT + 1) ? prod.y : 0.f;
+                    rwk_f2 zt[NP];
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        zt[p] = zp[p][ss][0] * xp[p][0];
+                        zt[p] = __builtin_elementwise_fma(zp[p][ss][1], xp[p][1], zt[p]);
+                        zt[p] = __builtin_elementwise_fma(zp[p][ss][2], xp[p][2], zt[p]);
+                        zt[p] = __builtin_elementwise_fma(zp[p][ss][3], xp[p][3], zt[p]);
                     }
-                    node2 += prod;
+                    const rwk_f2 zx2 = rwk_f2{zt[0].x, zt[0].x};
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        rwk_f2 prod = zt[p] * zx2;
+                        if (DROP) {
+                            prod.x = keep.at(ss * LT + 2 * p) ? prod.x : 0.f;
+                            prod.y = keep.at(ss * LT + 2 * p + 1) ? prod.y : 0.f;
+                        }
+                        node2[p] += prod;
+                    }
                 }
-                acc[0][0] += node2.x;
-                acc[1][0] += node2.y;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    acc[2 * p][0] += node2[p].x;
+                    acc[(2 * p + 1) % LT][0] += node2[p].y;
+                }
                 continue;
             }
             float xr[LT][DP];
@@ -355,7 +381,7 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
         }
         if (more) {
             // its readers all passed the previous barrier
-            if constexpr (kPairs) put_slot_pairs(tiles[buf ^ 1], slot, has_stream);
+            if constexpr (kPairs) put_slot_pairs<LT>(tiles[buf ^ 1], slot, has_stream);
             else put_slot<LT>(tiles[buf ^ 1], slot, has_stream);
             __syncthreads();
         }
@@ -421,19 +447,23 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     // two steps: the arithmetic runs on (step 0, step 1) pairs, one packed instruction for two of the scalar ones
     // (same operations on the same operands: same bits); dz2[ss][k] = (dZ_0[ss][k], dZ_1[ss][k]) is unpacked into
     // dz[] after the loop
-    constexpr bool kPairs = LT == 2 && !KS;
+    // (four steps only with sixteen lanes per stream: the run-time lane count's instance has no registers to spare)
+    constexpr bool kPairs = !KS && (LT == 2 || (LT == 4 && HPT == 16));
+    constexpr int NP = kPairs ? LT / 2 : 1;
     // ... and with sixteen lanes per stream the tile holds the rows interleaved (put_slot_pairs): the operand pairs
     // come out of the 16-byte LDS reads as they stand, and the dX totals are parked in the same interleaved places
-    constexpr bool kPairTile = kPairs && HPT == 16;
-    rwk_f2 zp[kPairs ? ST : 1][DP], dz2[kPairs ? ST : 1][DP];
+    constexpr bool kPairTile = kPairs && HPT == 16 && (LT == 2 || LT == 4);
+    rwk_f2 zp[NP][kPairs ? ST : 1][DP], dz2[NP][kPairs ? ST : 1][DP];
     if constexpr (kPairs) {
 #pragma unroll
-        for (int ss = 0; ss < ST; ++ss)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
-            for (int k = 0; k < DP; ++k) {
-                zp[ss][k] = rwk_f2{zr[0][ss][k], zr[1][ss][k]};
-                dz2[ss][k] = rwk_f2{0.f, 0.f};
-            }
+            for (int ss = 0; ss < ST; ++ss)
+#pragma unroll
+                for (int k = 0; k < DP; ++k) {
+                    zp[p][ss][k] = rwk_f2{zr[2 * p][ss][k], zr[2 * p + 1][ss][k]};
+                    dz2[p][ss][k] = rwk_f2{0.f, 0.f};
+                }
     }
     constexpr int SK = KS ? ST : 1;
     float dp_cur[LT][SK];
@@ -448,8 +478,11 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     if (HPT == 16 && (LT == 2 || LT == 4)) {
         const int idx = rwk_halving_index<(LT == 4 ? 16 : 8)>(lane_h);
         red_off = (((idx / DP) % LT) * kBlock + group0) * DP + idx % DP;      // in floats from &tile.x[0][0]
-        // interleaved rows (put_slot_pairs): value (i, k) is float (k % 2) * 2 + i of tile.x[k / 2][slot]
-        if (kPairTile) red_off = (((idx % DP) / 2) * kBlock + group0) * DP + ((idx % DP) % 2) * 2 + (idx / DP) % LT;
+        // interleaved rows (put_slot_pairs): value (i, k) is float (k % 2) * 2 + i % 2 of tile.x[2 (i / 2) + k / 2][slot]
+        if (kPairTile) {
+            const int i = (idx / DP) % LT, k = idx % DP;
+            red_off = ((2 * (i / 2) + k / 2) * kBlock + group0) * DP + (k % 2) * 2 + i % 2;
+        }
     }
     float bn_dl = 1.f;
     if constexpr (kFoldBuilt) if (fold) {
@@ -463,7 +496,7 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
             if ((tid & 7) == 0 && q < 2 * bn_c) s_bn[q < bn_c ? q : 32 + (q - bn_c)] = acc * bn_dl;
         }
     }
-    if constexpr (kPairTile) put_slot_pairs(tiles[0], slot, has_stream);
+    if constexpr (kPairTile) put_slot_pairs<LT>(tiles[0], slot, has_stream);
     else put_slot<LT>(tiles[0], slot, has_stream);
     __syncthreads();
     ProgressPriority priority(prio, stream_len);
@@ -486,8 +519,10 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
 #pragma unroll
             for (int i = 0; i < LT; ++i) {
                 const float4 v = tile.x[i][group0 + j];
-                if constexpr (kPairTile) {      // v = (x0[2i], x1[2i], x0[2i+1], x1[2i+1])
-                    xr[0][2 * i] = v.x; xr[1 % LT][2 * i] = v.y; xr[0][2 * i + 1] = v.z; xr[1 % LT][2 * i + 1] = v.w;
+                if constexpr (kPairTile) {      // with i = 2p + q: v = (x_2p[2q], x_2p+1[2q], x_2p[2q+1], x_2p+1[2q+1])
+                    constexpr int kOdd = LT > 1 ? 1 : 0;
+                    const int lo = i - i % 2, hi = lo + kOdd, q = i % 2;
+                    xr[lo][2 * q] = v.x; xr[hi][2 * q] = v.y; xr[lo][2 * q + 1] = v.z; xr[hi][2 * q + 1] = v.w;
                 } else {
                     xr[i][0] = v.x; xr[i][1] = v.y; xr[i][2] = v.z; xr[i][3] = v.w;
                 }
@@ -530,37 +565,53 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
             if constexpr (kPairs) {
                 Keep<NC> keep;
                 if (DROP) keep.draw(cfg, (uint32_t)node, (uint32_t)lane_h);
-                rwk_f2 xp[DP], dx2[DP];
+                rwk_f2 xp[NP][DP], dx2[NP][DP];
 #pragma unroll
-                for (int k = 0; k < DP; ++k) {
-                    xp[k] = rwk_f2{xr[0][k], xr[1][k]};
-                    dx2[k] = rwk_f2{0.f, 0.f};
-                }
-#pragma unroll
-                for (int ss = 0; ss < ST; ++ss) {
-                    rwk_f2 zt = zp[ss][0] * xp[0];                                  // (zx, t)
-                    zt = __builtin_elementwise_fma(zp[ss][1], xp[1], zt);
-                    zt = __builtin_elementwise_fma(zp[ss][2], xp[2], zt);
-                    zt = __builtin_elementwise_fma(zp[ss][3], xp[3], zt);
-                    float w0 = dp_cur[0][0], w1 = dp_cur[1][0];
-                    if (DROP) {
-                        w0 = keep.at(ss * LT) ? w0 : 0.f;
-                        w1 = keep.at(ss * LT + 1) ? w1 : 0.f;
-                    }
-                    float dzx = 2.f * w0 * zt.x;          // step 0 contributes keep * zx^2
-                    dzx = fmaf(w1, zt.y, dzx);
-                    const rwk_f2 cf = rwk_f2{dzx, w1 * zt.x};                       // (d zx, d t)
+                for (int p = 0; p < NP; ++p)
 #pragma unroll
                     for (int k = 0; k < DP; ++k) {
-                        dx2[k] = __builtin_elementwise_fma(cf, zp[ss][k], dx2[k]);
-                        dz2[ss][k] = __builtin_elementwise_fma(cf, xp[k], dz2[ss][k]);
+                        xp[p][k] = rwk_f2{xr[2 * p][k], xr[(2 * p + 1) % LT][k]};
+                        dx2[p][k] = rwk_f2{0.f, 0.f};
                     }
+#pragma unroll
+                for (int ss = 0; ss < ST; ++ss) {
+                    rwk_f2 zt[NP];                                                  // (zx, t_1), (t_2, t_3), ...
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        zt[p] = zp[p][ss][0] * xp[p][0];
+                        zt[p] = __builtin_elementwise_fma(zp[p][ss][1], xp[p][1], zt[p]);
+                        zt[p] = __builtin_elementwise_fma(zp[p][ss][2], xp[p][2], zt[p]);
+                        zt[p] = __builtin_elementwise_fma(zp[p][ss][3], xp[p][3], zt[p]);
+                    }
+                    float w[LT];
+#pragma unroll
+                    for (int i = 0; i < LT; ++i) {
+                        w[i] = dp_cur[i][0];
+                        if (DROP) w[i] = keep.at(ss * LT + i) ? w[i] : 0.f;
+                    }
+                    const float zx = zt[0].x;
+                    float dzx = 2.f * w[0] * zx;          // step 0 contributes keep * zx^2
+#pragma unroll
+                    for (int i = 1; i < LT; ++i) dzx = fmaf(w[i], i % 2 ? zt[i / 2].y : zt[i / 2].x, dzx);
+                    rwk_f2 cf[NP];                                                  // (d zx, d t_1), (d t_2, d t_3), ...
+                    cf[0] = rwk_f2{dzx, w[1 % LT] * zx};
+#pragma unroll
+                    for (int p = 1; p < NP; ++p) cf[p] = rwk_f2{w[2 * p], w[(2 * p + 1) % LT]} * rwk_f2{zx, zx};
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+#pragma unroll
+                        for (int k = 0; k < DP; ++k) {
+                            dx2[p][k] = __builtin_elementwise_fma(cf[p], zp[p][ss][k], dx2[p][k]);
+                            dz2[p][ss][k] = __builtin_elementwise_fma(cf[p], xp[p][k], dz2[p][ss][k]);
+                        }
                 }
 #pragma unroll
-                for (int k = 0; k < DP; ++k) {
-                    dxr[0][k] = dx2[k].x;
-                    dxr[1][k] = dx2[k].y;
-                }
+                for (int p = 0; p < NP; ++p)
+#pragma unroll
+                    for (int k = 0; k < DP; ++k) {
+                        dxr[2 * p][k] = dx2[p][k].x;
+                        dxr[(2 * p + 1) % LT][k] = dx2[p][k].y;
+                    }
             } else {
                 Keep<NC> keep;
                 if (DROP) keep.draw(cfg, (uint32_t)node, (uint32_t)lane_h);
@@ -617,9 +668,9 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
 #pragma unroll
             for (int i = 0; i < LT; ++i) {
                 float4 mv = tile.x[i][tid];               // written by a lane of this wavefront
-                if constexpr (kPairTile) {                // de-interleave: row i = float i of every pair
-                    const float4 ma = tile.x[0][tid], mb = tile.x[1 % LT][tid];
-                    mv = i == 0 ? make_float4(ma.x, ma.z, mb.x, mb.z) : make_float4(ma.y, ma.w, mb.y, mb.w);
+                if constexpr (kPairTile) {                // de-interleave: row i = float i % 2 of every pair
+                    const float4 ma = tile.x[i - i % 2][tid], mb = tile.x[(i - i % 2 + 1) % LT][tid];
+                    mv = i % 2 == 0 ? make_float4(ma.x, ma.z, mb.x, mb.z) : make_float4(ma.y, ma.w, mb.y, mb.w);
                 }
                 const float mine_i[DP] = {mv.x, mv.y, mv.z, mv.w};
                 float *row = dx + i * step_stride + (size_t)my_node * d;
@@ -634,7 +685,7 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
         }
         if (more) {
             // its readers all passed the previous barrier
-            if constexpr (kPairTile) put_slot_pairs(tiles[buf ^ 1], slot, has_stream);
+            if constexpr (kPairTile) put_slot_pairs<LT>(tiles[buf ^ 1], slot, has_stream);
             else put_slot<LT>(tiles[buf ^ 1], slot, has_stream);
             __syncthreads();
         }
@@ -643,12 +694,14 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     RWK_STAMP_AT(3);
     if constexpr (kPairs) {
 #pragma unroll
-        for (int ss = 0; ss < ST; ++ss)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
-            for (int k = 0; k < DP; ++k) {
-                dz[ss * DP + k] = dz2[ss][k].x;
-                dz[(ST + ss) * DP + k] = dz2[ss][k].y;
-            }
+            for (int ss = 0; ss < ST; ++ss)
+#pragma unroll
+                for (int k = 0; k < DP; ++k) {
+                    dz[(2 * p * ST + ss) * DP + k] = dz2[p][ss][k].x;
+                    dz[(((2 * p + 1) % LT) * ST + ss) * DP + k] = dz2[p][ss][k].y;
+                }
     }
     // per-workgroup partial of dZ: threads that own the same hidden graph are added in thread order
     const int spb = kBlock / hp;
