@@ -14,7 +14,7 @@ constexpr int kBlock = 256;
 static_assert(kHiddenBlock == kBlock && kProjectBlock == kBlock, "the merged launches use one workgroup size");
 constexpr size_t kLdsLimit = 160 * 1024;
 // Column sums of a (p, v) matrix with v <= 64 by one workgroup of 256 threads: 256 / vp lanes per column (vp = v
-// rounded up to a power of two), lane l adds rows l, l + lanes, ... in order (four loads in flight), then the lanes of
+// rounded up to a power of two), lane l adds rows l, l + lanes, ... in order (sixteen loads in flight), then the lanes of
 // a column are added in a fixed halving tree.  lds: 256 floats.
 struct NoSumTail {
     __device__ inline void column(int /*col*/, float /*sum*/) const {}
@@ -27,16 +27,17 @@ __device__ inline void reduce_rows_small256_body(float *red, const float *__rest
     const int colv = tid % vp, lane = tid / vp, lanes = kBlock / vp;
     const int cc = colv < v ? colv : v - 1;
     float acc = 0.f;
-    for (int r0 = lane; r0 < p; r0 += 4 * lanes) {
-        float a[4];
+    constexpr int kFlight = 16;      // loads in flight per round (a lane's rows are still added in row order)
+    for (int r0 = lane; r0 < p; r0 += kFlight * lanes) {
+        float a[kFlight];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kFlight; ++u) {
             const int r = r0 + u * lanes;
             a[u] = in[(size_t)(r < p ? r : p - 1) * v + cc];
             if (r >= p) a[u] = 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc += a[u];
+        for (int u = 0; u < kFlight; ++u) acc += a[u];
     }
     red[tid] = acc;
     __syncthreads();
