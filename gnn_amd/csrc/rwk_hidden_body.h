@@ -160,8 +160,11 @@ __device__ inline void hidden_backward_body(int h, float *lds, const float *__re
         d_feat[(size_t)h * sd + i] = dz[i];
         tail.features_hidden((long long)h * sd + i, dz[i]);
     }
+    // the entries of adj_hidden are finished by the threads at the top of the workgroup, those of features_hidden by the
+    // threads at the bottom: with a tail attached (an Adam update per element: three divisions and a square root in a
+    // dependent chain) the two run in different wavefronts, side by side, instead of one after the other
     const int n_pairs = s * (s - 1) / 2;
-    for (int k = tid; k < n_pairs; k += kBlock) {
+    for (int k = kBlock - 1 - tid; k < n_pairs; k += kBlock) {
         int r, c;
         triu_pair(k, s, &r, &c);
         const float a = adj_hidden[(size_t)h * n_pairs + k];
