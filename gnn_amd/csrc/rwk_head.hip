@@ -1523,6 +1523,16 @@ head_train32_kernel(const float *__restrict__ k, HeadDims dm, const float *__res
     HEAD_STAMP_AT(27);
 }
 
+// Workgroups of the finishing launch: at least the tile count (each finishes the dK rows of its tiles), and enough
+// of them that a workgroup's slice of the parameter gradients is at most the 32 elements whose partial rows it fetches
+// in one round - with few graphs (8 tiles for a batch of 64) a workgroup otherwise walks hundreds of elements, a round
+// trip per 32 (13 us on such a batch).  An element's sum does not depend on which workgroup forms it.
+inline int finish_grid(int tiles, int c, int p, int nc) {
+    const int by_elements = (head_nv(c, p, nc) + kBlock / 8 - 1) / (kBlock / 8);
+    const int want = by_elements < 256 ? by_elements : 256;
+    return tiles > want ? tiles : want;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // backward, second launch: parameter gradients (block partials added in block order) and dK
 // ---------------------------------------------------------------------------------------------------
@@ -1928,9 +1938,9 @@ int rwk_head_backward_loss(const float *k, int64_t g, int64_t c, int64_t p, int6
                        w1, w2, h1d, out, d_out, keep_scale, dy, partials, (const long long *)labels, d_loss,
                        loss_partials, blocks, loss);
     RWK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(head_bwd_finish_kernel, dim3(blocks), dim3(kBlock), 0, stream, k, dm, bn_w, mean, invstd, dy,
-                       partials, blocks, training, grads, d_k, (const float *)nullptr, (const float *)nullptr,
-                       (float *)nullptr);
+    hipLaunchKernelGGL(head_bwd_finish_kernel, dim3(finish_grid(blocks, (int)c, (int)p, (int)nc)), dim3(kBlock), 0,
+                       stream, k, dm, bn_w, mean, invstd, dy, partials, blocks, training, grads, d_k,
+                       (const float *)nullptr, (const float *)nullptr, (float *)nullptr);
     RWK_LAUNCH_CHECK();
     return RWK_OK;
 }
@@ -2019,8 +2029,9 @@ int rwk_head_train_backward(const float *k, int64_t g, int64_t c, int64_t p, int
     if (!rwk_head_train_supported(g, c, p, nc)) return RWK_E_UNSUPPORTED;
     const int blocks = head_blocks(g);
     const HeadDims dm{(long long)g, (int)c, (int)p, (int)nc};
-    hipLaunchKernelGGL(head_bwd_finish_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream_, k, dm, bn_w, mean,
-                       invstd, dy, partials, blocks, 1, grads, d_k, d_loss, loss_partials, loss);
+    hipLaunchKernelGGL(head_bwd_finish_kernel, dim3(finish_grid(blocks, (int)c, (int)p, (int)nc)), dim3(kBlock), 0,
+                       (hipStream_t)stream_, k, dm, bn_w, mean, invstd, dy, partials, blocks, 1, grads, d_k, d_loss,
+                       loss_partials, loss);
     RWK_LAUNCH_CHECK();
     return RWK_OK;
 }
