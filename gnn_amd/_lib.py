@@ -82,11 +82,11 @@ SIGNATURES = {
     "rwk_step_tail_n_counters": (_I64, [_I64, _I64, _I64]),
     "rwk_hidden_backward_reduce_adam": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _I64, _I64,
                                                 _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _I64, _I64, _P,
-                                                c_float, c_float, c_float, c_float, _P, _P]),
+                                                c_float, c_float, c_float, c_float, _P, _P, _P]),
     "rwk_step_tail_n_counters_head": (_I64, [_I64, _I64, _I64]),
     "rwk_hidden_backward_reduce_adam_head": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _I64,
                                                      _I64, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _I64,
-                                                     _I64, _P, c_float, c_float, c_float, c_float, _P, _P, _I64, _I64,
+                                                     _I64, _P, c_float, c_float, c_float, c_float, _P, _P, _P, _I64, _I64,
                                                      _P, _P, _P, _P, _I64, _P]),
     "rwk_fused_backward_bn_supported": (c_int, [_I64, _I64, _I64, _I64]),
     "rwk_fused_backward_bn": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_float, c_int, _P, _P,

@@ -81,6 +81,10 @@ struct AdamTailArgs {
     long long *counters;
     long long off_adj, off_feat, off_red;                // flat index of adj_hidden[0], features_hidden[0], column 0
     long long rest_off, n;                               // the chunked remainder covers [rest_off, n)
+    // Two slots of {step count t as int64, the two bias corrections of step t as two floats in an int64}; step t uses
+    // slot t & 1.  Written for the NEXT step (into the other slot, which nobody reads during this launch) by the
+    // column-sum workgroup, which ends well before the hidden-graph workgroups.  May be null.
+    long long *corr_slot;
     const float *src[kTailChunks];
     long long off[kTailChunks];                          // flat index each chunk starts at; unused: LLONG_MAX
 };
@@ -144,11 +148,34 @@ hidden_backward_reduce_adam_kernel(const float *__restrict__ adj_hidden, const f
                                    HeadSumArgs hs) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float corr[2];
+    // The bias corrections are double-precision power loops and a root: 0.6 us in one thread, on the critical path of
+    // every workgroup (the others wait for it at the first barrier).  The previous step's launch left them in
+    // corr_slot, computed by a workgroup that had time to spare; a slot of another step count (first step, another
+    // launch shape in between) is ignored and the values are computed here, with the same operations.
     if (threadIdx.x == 0 && a.param != nullptr) {
+        // both slots are requested together with the counter (a slot address that waited for t would cost the round
+        // trip the hand-over is meant to save)
+        long long sl[4] = {0, 0, 0, 0};
+        if (a.corr_slot != nullptr) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sl[q] = a.corr_slot[q];
+        }
         const long long t = a.counters[blockIdx.x] + 1;
         a.counters[blockIdx.x] = t;
-        corr[0] = (float)(1.0 - pow_int((double)a.beta1, t));
-        corr[1] = (float)sqrt(1.0 - pow_int((double)a.beta2, t));
+        bool have = false;
+        if (a.corr_slot != nullptr) {
+            const long long t_slot = (t & 1) ? sl[2] : sl[0];
+            const long long packed = (t & 1) ? sl[3] : sl[1];
+            if (t_slot == t) {
+                corr[0] = __int_as_float((int)(packed & 0xFFFFFFFFll));
+                corr[1] = __int_as_float((int)(packed >> 32));
+                have = true;
+            }
+        }
+        if (!have) {
+            corr[0] = (float)(1.0 - pow_int((double)a.beta1, t));
+            corr[1] = (float)sqrt(1.0 - pow_int((double)a.beta2, t));
+        }
     }
     const int b = blockIdx.x;
     if (b < n_hidden) {
@@ -157,6 +184,15 @@ hidden_backward_reduce_adam_kernel(const float *__restrict__ adj_hidden, const f
                              d_adj_hidden, d_feat_hidden, n_slices, HiddenAdamTail{a, corr});
     } else if (b == n_hidden) {
         reduce_rows_small256_body(lds, red_in, red_p, red_v, red_vp, red_out, SumAdamTail{a, corr});
+        // the next step's bias corrections, for every workgroup of the next launch (read there before anything here is
+        // overwritten: launches on one stream do not overlap)
+        if (threadIdx.x == 0 && a.param != nullptr && a.corr_slot != nullptr) {
+            const long long t1 = a.counters[blockIdx.x] + 1;          // this workgroup's counter already holds t
+            const float c0 = (float)(1.0 - pow_int((double)a.beta1, t1));
+            const float c1 = (float)sqrt(1.0 - pow_int((double)a.beta2, t1));
+            a.corr_slot[2 * (t1 & 1) + 1] = (long long)(unsigned int)__float_as_int(c0) | ((long long)__float_as_int(c1) << 32);
+            a.corr_slot[2 * (t1 & 1)] = t1;
+        }
     } else if (hs.partials == nullptr) {
         const long long i = a.rest_off + (long long)(b - n_hidden - 1) * kBlock + threadIdx.x;
         const long long ic = i < a.n ? i : a.n - 1;
@@ -283,7 +319,8 @@ static int step_tail_launch(const float *adj_hidden, const float *ah, const floa
                             float *grad_out, int64_t n, int64_t off_adj, int64_t off_feat, int64_t off_red,
                             const float *const *rest_srcs, const int64_t *rest_sizes, int64_t n_rest,
                             int64_t rest_off, const float *lr, float beta1, float beta2, float eps,
-                            float weight_decay, int64_t *step_counters, const HeadSumArgs &hs, rwk_stream_t stream_) {
+                            float weight_decay, int64_t *step_counters, int64_t *corr_slot, const HeadSumArgs &hs,
+                            rwk_stream_t stream_) {
     RWK_REQUIRE_PTR(adj_hidden);
     RWK_REQUIRE_PTR(ah);
     RWK_REQUIRE_PTR(z);
@@ -321,6 +358,7 @@ static int step_tail_launch(const float *adj_hidden, const float *ah, const floa
     a.param = param; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.grad_out = grad_out; a.lr = lr;
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
     a.counters = (long long *)step_counters;
+    a.corr_slot = (long long *)corr_slot;
     a.off_adj = off_adj; a.off_feat = off_feat; a.off_red = off_red; a.rest_off = rest_off; a.n = n;
     long long off = rest_off;
     for (int k = 0; k < kTailChunks; ++k) {
@@ -353,11 +391,11 @@ int rwk_hidden_backward_reduce_adam(const float *adj_hidden, const float *ah, co
                                     float *grad_out, int64_t n, int64_t off_adj, int64_t off_feat, int64_t off_red,
                                     const float *const *rest_srcs, const int64_t *rest_sizes, int64_t n_rest,
                                     int64_t rest_off, const float *lr, float beta1, float beta2, float eps,
-                                    float weight_decay, int64_t *step_counters, rwk_stream_t stream_) {
+                                    float weight_decay, int64_t *step_counters, int64_t *corr_slot, rwk_stream_t stream_) {
     return step_tail_launch(adj_hidden, ah, z, dz_partials, n_partials, h, s, d, max_step, d_adj_hidden,
                             d_features_hidden, red_in, red_p, red_v, red_out, param, exp_avg, exp_avg_sq, grad_out, n,
                             off_adj, off_feat, off_red, rest_srcs, rest_sizes, n_rest, rest_off, lr, beta1, beta2, eps,
-                            weight_decay, step_counters, HeadSumArgs{}, stream_);
+                            weight_decay, step_counters, corr_slot, HeadSumArgs{}, stream_);
 }
 
 int rwk_hidden_backward_reduce_adam_head(const float *adj_hidden, const float *ah, const float *z,
@@ -368,7 +406,8 @@ int rwk_hidden_backward_reduce_adam_head(const float *adj_hidden, const float *a
                                          int64_t off_adj, int64_t off_feat, int64_t off_red,
                                          const int64_t *rest_columns, const int64_t *rest_sizes, int64_t n_rest,
                                          int64_t rest_off, const float *lr, float beta1, float beta2, float eps,
-                                         float weight_decay, int64_t *step_counters, const float *head_partials,
+                                         float weight_decay, int64_t *step_counters, int64_t *corr_slot,
+                                         const float *head_partials,
                                          int64_t n_head_partials, int64_t head_nv, const float *d_loss,
                                          float *head_grads_out, const float *loss_partials, float *loss_out,
                                          int64_t n_graphs, rwk_stream_t stream_) {
@@ -390,7 +429,7 @@ int rwk_hidden_backward_reduce_adam_head(const float *adj_hidden, const float *a
     return step_tail_launch(adj_hidden, ah, z, dz_partials, n_partials, h, s, d, max_step, d_adj_hidden,
                             d_features_hidden, red_in, red_p, red_v, red_out, param, exp_avg, exp_avg_sq, grad_out, n,
                             off_adj, off_feat, off_red, srcs, rest_sizes, n_rest, rest_off, lr, beta1, beta2, eps,
-                            weight_decay, step_counters, hs, stream_);
+                            weight_decay, step_counters, corr_slot, hs, stream_);
 }
 
 }  // extern "C"

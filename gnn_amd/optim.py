@@ -118,6 +118,11 @@ class StepTail:
         n_counters = max(int(lib.rwk_step_tail_n_counters(n_hidden, self.n, self.rest_off)),
                          int(lib.rwk_step_tail_n_counters_head(n_hidden, self.n, self.rest_off)))
         dev = opt.flat_param.device
+        # hand-over of Adam's bias corrections from one step's launch to the next (rwk.h: corr_slot);
+        # RWK_NO_CORR_SLOT=1 switches it off (every workgroup then computes its own, as the stand-alone kernels do)
+        import os
+        self.corr_slot = None if os.environ.get("RWK_NO_CORR_SLOT") == "1" else torch.zeros(4, dtype=torch.int64,
+                                                                                              device=dev)
         # one counter per workgroup of either launch shape, all at the optimiser's step count: the two shapes may
         # then alternate (the counters one shape does not touch are brought along by sync_counters)
         if not self.update:
@@ -180,7 +185,8 @@ class StepTail:
                 adj_hidden, ah, z, dz, dz_rows, n_hidden, s, d, steps, d_adj, d_feat, partials, blocks, red_v, red_out,
                 upd(o.flat_param), upd(o.exp_avg), upd(o.exp_avg_sq), o.bucket.flat.data_ptr(),
                 self.n, self.off_adj, self.off_feat, self.off_red, cols, sizes, n, self.rest_off, upd(o.lr),
-                o.betas[0], o.betas[1], o.eps, o.weight_decay, upd(self.counters), hp_.data_ptr(), hp_.shape[0],
+                o.betas[0], o.betas[1], o.eps, o.weight_decay, upd(self.counters), _lib.ptr(self.corr_slot),
+                hp_.data_ptr(), hp_.shape[0],
                 hp_.shape[1], head_fold["d_loss"].data_ptr(), head_fold["grads"].data_ptr(),
                 head_fold["loss_partials"].data_ptr(), head_fold["loss"].data_ptr(), int(n_graphs), stream),
                 "rwk_hidden_backward_reduce_adam_head")
@@ -192,5 +198,6 @@ class StepTail:
             adj_hidden, ah, z, dz, dz_rows, n_hidden, s, d, steps, d_adj, d_feat, partials, blocks, red_v, red_out,
             upd(o.flat_param), upd(o.exp_avg), upd(o.exp_avg_sq), o.bucket.flat.data_ptr(), self.n,
             self.off_adj, self.off_feat, self.off_red, srcs, sizes, n, self.rest_off, upd(o.lr), o.betas[0],
-            o.betas[1], o.eps, o.weight_decay, upd(self.counters), stream), "rwk_hidden_backward_reduce_adam")
+            o.betas[1], o.eps, o.weight_decay, upd(self.counters), _lib.ptr(self.corr_slot), stream),
+            "rwk_hidden_backward_reduce_adam")
         self.done = True

@@ -435,7 +435,10 @@ int rwk_hidden_backward_reduce(const float *adj_hidden, const float *ah, const f
  * rwk_step_tail_n_counters(h, n, rest_off) int64 at one common step count (each workgroup advances its own).
  * param == NULL: no update (exp_avg, exp_avg_sq, lr, step_counters are not touched and may be NULL); the launch then
  * only completes the flat gradient in grad_out (required) - the data-parallel step, whose all-reduce and
- * rwk_adam_step follow. */
+ * rwk_adam_step follow.  corr_slot (may be NULL): four int64 of device memory, zeroed once, that the launches of
+ * consecutive steps hand Adam's two bias corrections through: the column-sum workgroup, which ends early, computes the
+ * next step's pair (double-precision power loops and a root, 0.6 us in one thread) so that the next launch's
+ * workgroups need not; a slot whose step count does not match is ignored. */
 int64_t rwk_step_tail_n_counters(int64_t h, int64_t n, int64_t rest_off);
 int rwk_hidden_backward_reduce_adam(const float *adj_hidden, const float *ah, const float *z, const float *dz_partials,
                                     int64_t n_partials, int64_t h, int64_t s, int64_t d, int64_t max_step,
@@ -444,7 +447,7 @@ int rwk_hidden_backward_reduce_adam(const float *adj_hidden, const float *ah, co
                                     float *grad_out, int64_t n, int64_t off_adj, int64_t off_feat, int64_t off_red,
                                     const float *const *rest_srcs, const int64_t *rest_sizes, int64_t n_rest,
                                     int64_t rest_off, const float *lr, float beta1, float beta2, float eps,
-                                    float weight_decay, int64_t *step_counters, rwk_stream_t stream);
+                                    float weight_decay, int64_t *step_counters, int64_t *corr_slot, rwk_stream_t stream);
 
 /* The same launch when the head's finishing launch (rwk_head_train_backward) is left out and its batch-norm part
  * runs inside rwk_fused_backward_bn: the n_rest remaining tensors are the head's parameters, and their gradients are
@@ -464,7 +467,8 @@ int rwk_hidden_backward_reduce_adam_head(const float *adj_hidden, const float *a
                                          int64_t off_adj, int64_t off_feat, int64_t off_red,
                                          const int64_t *rest_columns, const int64_t *rest_sizes, int64_t n_rest,
                                          int64_t rest_off, const float *lr, float beta1, float beta2, float eps,
-                                         float weight_decay, int64_t *step_counters, const float *head_partials,
+                                         float weight_decay, int64_t *step_counters, int64_t *corr_slot,
+                                         const float *head_partials,
                                          int64_t n_head_partials, int64_t head_nv, const float *d_loss,
                                          float *head_grads_out, const float *loss_partials, float *loss_out,
                                          int64_t n_graphs, rwk_stream_t stream);
