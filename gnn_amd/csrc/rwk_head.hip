@@ -265,20 +265,22 @@ kreduce_stats_kernel(const float *__restrict__ k_partials, const int *__restrict
     }
 }
 
-// The same reduction when a block owns a single row (at most kMaxFusedStatsBlocks graphs in the batch): the row's slots
-// are consecutive rows of c floats in k_partials, so the whole workgroup copies them to LDS as one coalesced stream,
-// every load in flight at once, and the thread of a column then adds them from LDS in slot order - the same additions
-// in the same order as kreduce_stats_kernel, which walks a row's slots sixteen at a time with one thread per column: a
+// The same reduction when a block owns few rows (at most kKrSeqRows: batches of up to 512 graphs).  A row's slots are
+// consecutive rows of c floats in k_partials, so the whole workgroup copies them to LDS as one coalesced stream, every
+// load in flight at once, and the thread of a column then adds them from LDS in slot order - the same additions in the
+// same order as kreduce_stats_kernel, which walks a row's slots sixteen at a time with one thread per (row, column): a
 // batch of 64 power-law graphs of 3000 nodes (150 slots per graph) took it ten dependent round trips, 56 us.  The
-// statistics of a one-row block are exact: count 1, mean = the value, M2 = 0.
+// block's rows are taken one after the other; the thread of a column keeps their values for the statistics (folded
+// into the many-rows kernel, with eight rows per block in sequence, this form was slower on every batch).
 constexpr int kKrRowChunk = 8192;            // floats of LDS per chunk of slots
 constexpr int kKrRowFlight = 16;             // loads in flight per thread and round
+constexpr int kKrSeqRows = 4;                // rows per block up to which this kernel is used
 
 __global__ void __launch_bounds__(kBlock)
 kreduce_stats_row_kernel(const float *__restrict__ k_partials, const int *__restrict__ seg_ptr,
                          const float *__restrict__ counts_f32, long long g, int c, int stream_len, float scale,
-                         int normalize, float *k, float *__restrict__ partials, unsigned long long *rng_state,
-                         unsigned long long *rng_used) {
+                         int normalize, int rows_per_block, float *k, float *__restrict__ partials,
+                         unsigned long long *rng_state, unsigned long long *rng_used) {
     __shared__ float chunk[kKrRowChunk];
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0 && rng_state != nullptr && rng_used != nullptr) {
@@ -287,43 +289,66 @@ kreduce_stats_row_kernel(const float *__restrict__ k_partials, const int *__rest
         rng_used[1] = off;
         rng_state[1] = off + 1ull;
     }
-    const long long row = blockIdx.x;
-    if (row >= g) return;
-    const int first = seg_ptr[row] / stream_len, last = (seg_ptr[row + 1] - 1) / stream_len;
-    const int n_slots = last - first + 1;
-    const float *src = k_partials + ((size_t)row + first) * c;       // slot `first` of this row; the next ones follow
+    const long long r_lo = (long long)blockIdx.x * rows_per_block;
+    const long long r_hi = r_lo + rows_per_block < g ? r_lo + rows_per_block : g;
+    if (r_lo >= r_hi) return;
     const int slots_per_chunk = kKrRowChunk / c;
-    float acc = 0.f;
-    for (int s0 = 0; s0 < n_slots; s0 += slots_per_chunk) {            // uniform over the workgroup
-        const int n_ch = n_slots - s0 < slots_per_chunk ? n_slots - s0 : slots_per_chunk;
-        const int total = n_ch * c;
-        const float *from = src + (size_t)s0 * c;
-        for (int e0 = tid; e0 < total; e0 += kKrRowFlight * kBlock) {
-            float v[kKrRowFlight];
+    float vals[kKrSeqRows];
+    float sum = 0.f;
 #pragma unroll
-            for (int u = 0; u < kKrRowFlight; ++u) {
-                const int e = e0 + u * kBlock;
-                v[u] = from[e < total ? e : total - 1];
-            }
+    for (int q = 0; q < kKrSeqRows; ++q) {
+        vals[q] = 0.f;
+        const long long row = r_lo + q;
+        if (row >= r_hi) continue;                                       // uniform over the workgroup
+        const int first = seg_ptr[row] / stream_len, last = (seg_ptr[row + 1] - 1) / stream_len;
+        const int n_slots = last - first + 1;
+        const float *src = k_partials + ((size_t)row + first) * c;     // slot `first` of this row; the next ones follow
+        float acc = 0.f;
+        for (int s0 = 0; s0 < n_slots; s0 += slots_per_chunk) {          // uniform over the workgroup
+            const int n_ch = n_slots - s0 < slots_per_chunk ? n_slots - s0 : slots_per_chunk;
+            const int total = n_ch * c;
+            const float *from = src + (size_t)s0 * c;
+            for (int e0 = tid; e0 < total; e0 += kKrRowFlight * kBlock) {
+                float v[kKrRowFlight];
 #pragma unroll
-            for (int u = 0; u < kKrRowFlight; ++u) {
-                const int e = e0 + u * kBlock;
-                if (e < total) chunk[e] = v[u];
+                for (int u = 0; u < kKrRowFlight; ++u) {
+                    const int e = e0 + u * kBlock;
+                    v[u] = from[e < total ? e : total - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < kKrRowFlight; ++u) {
+                    const int e = e0 + u * kBlock;
+                    if (e < total) chunk[e] = v[u];
+                }
             }
+            __syncthreads();
+            if (tid < c)
+                for (int sl = 0; sl < n_ch; ++sl) acc += chunk[sl * c + tid];
+            __syncthreads();
         }
-        __syncthreads();
-        if (tid < c)
-            for (int sl = 0; sl < n_ch; ++sl) acc += chunk[sl * c + tid];
-        __syncthreads();
+        if (tid < c) {
+            float v = acc * scale;
+            if (normalize) v /= counts_f32[row];
+            k[row * c + tid] = v;
+            vals[q] = v;
+            sum += v;
+        }
     }
     if (tid < c) {
-        float v = acc * scale;
-        if (normalize) v /= counts_f32[row];
-        k[row * c + tid] = v;
+        const long long count = r_hi - r_lo;
+        const float mu = sum / (float)count;
+        float m2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < kKrSeqRows; ++q) {
+            if (r_lo + q < r_hi) {
+                const float dv = vals[q] - mu;
+                m2 = fmaf(dv, dv, m2);
+            }
+        }
         float *out = partials + (size_t)blockIdx.x * stats_stride(c);
-        if (tid == 0) out[0] = 1.f;
-        out[4 + tid] = v;
-        out[4 + c + tid] = 0.f;
+        if (tid == 0) out[0] = (float)count;
+        out[4 + tid] = mu;
+        out[4 + c + tid] = m2;
     }
 }
 
@@ -1795,10 +1820,9 @@ int64_t rwk_fused_reduce_stats_rows(int64_t g, int64_t c) {
     // one row per block while the blocks stay within what the head merges (kreduce_stats_row_kernel: every slot of a
     // graph in flight at once, whatever the graph's size), else at least eight
     if (g <= kMaxFusedStatsBlocks) return 1;
-    int64_t min_rows = 8;
-    if (min_rows > g) min_rows = g;
-    const int64_t rows = (g + kMaxFusedStatsBlocks - 1) / kMaxFusedStatsBlocks;
-    return rows < min_rows ? min_rows : rows;
+    // beyond that as few rows per block as keep the blocks within that number: the reduction is latency-bound, more
+    // workgroups with fewer rows each end sooner (256 power-law graphs: 44 us at eight rows per block)
+    return (g + kMaxFusedStatsBlocks - 1) / kMaxFusedStatsBlocks;
 }
 
 int64_t rwk_fused_reduce_stats_blocks(int64_t g, int64_t c) {
@@ -1822,11 +1846,11 @@ int rwk_fused_reduce_stats(const float *k_partials, const int32_t *seg_ptr, cons
     if (c > kMaxC || n_graphs >= (int64_t)1 << 40) return RWK_E_UNSUPPORTED;
     const float scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     const int64_t rows = rwk_fused_reduce_stats_rows(n_graphs, c);
-    if (rows == 1)
+    if (rows <= kKrSeqRows)
         hipLaunchKernelGGL(kreduce_stats_row_kernel, dim3((unsigned)rwk_fused_reduce_stats_blocks(n_graphs, c)),
                            dim3(kBlock), 0, (hipStream_t)stream, k_partials, seg_ptr, counts_f32, (long long)n_graphs,
-                           (int)c, (int)stream_len, scale, normalize, k, stats, (unsigned long long *)rng_state,
-                           (unsigned long long *)rng_used);
+                           (int)c, (int)stream_len, scale, normalize, (int)rows, k, stats,
+                           (unsigned long long *)rng_state, (unsigned long long *)rng_used);
     else
         hipLaunchKernelGGL(kreduce_stats_kernel, dim3((unsigned)rwk_fused_reduce_stats_blocks(n_graphs, c)),
                            dim3(kBlock), 0, (hipStream_t)stream, k_partials, seg_ptr, counts_f32, (long long)n_graphs,
