@@ -574,16 +574,6 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                 int nd[4];                                    // nodes of the dX rows this lane will store
 #pragma unroll
                 for (int r = 0; r < 4; ++r) nd[r] = t_node[buf * 16 + 4 * q + r];
-                // dX so far (earlier blocks of hidden graphs): requested now, added after the MFMAs.  Agent-scope
-                // loads: the element was stored by this very lane, but a plain load could hit a stale L1 line.
-                const int kcol = 16 * tc + col < d ? 16 * tc + col : d - 1;
-                float old[4] = {0.f, 0.f, 0.f, 0.f};
-                if (hb > 0) {                                 // uniform
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        old[r] = __hip_atomic_load(dx_out + (size_t)i * step_stride + (size_t)(nd[r] >= 0 ? nd[r] : 0) * d + kcol,
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
                 f32x4 dxa = {0.f, 0.f, 0.f, 0.f};
                 // operands of hidden node ss: ga = G_i[ss][node = col][h = 4q..4q+3] (A of dX),
                 // zb[r] = Z_i[ss][h = 4q + r][16tc + col] (B of dX), gb[r] = G_i[ss][h = col][node = 4q + r] (A of dZ)
@@ -629,8 +619,15 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                 const int k = 16 * tc + col;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (nd[r] >= 0 && k < d)
-                        dx_out[(size_t)i * step_stride + (size_t)nd[r] * d + k] = old[r] + dxa[r];
+                    if (nd[r] >= 0 && k < d) {
+                        // first block of hidden graphs: store; later blocks: add at the L2, in block order (the
+                        // element's owner lane issues them one after the other)
+                        float *dst = dx_out + (size_t)i * step_stride + (size_t)nd[r] * d + k;
+                        if (hb > 0)
+                            (void)__hip_atomic_fetch_add(dst, dxa[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else
+                            *dst = dxa[r];
+                    }
                 }
             }
         }
@@ -906,17 +903,6 @@ backward_pipe_kernel(const float *__restrict__ x, const float *__restrict__ z, c
                 int nd[4];                                    // nodes of the dX rows this lane will store
 #pragma unroll
                 for (int r = 0; r < 4; ++r) nd[r] = tn[4 * q + r];
-                // dX so far (earlier blocks of hidden graphs): requested now, added after the MFMAs.  Agent-scope
-                // loads: the element was stored by this very lane, but a plain load could hit a stale L1 line.
-                const int kcol = 16 * tc + col < d ? 16 * tc + col : d - 1;
-                float old[4] = {0.f, 0.f, 0.f, 0.f};
-                if (hb > 0) {                                 // uniform
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        old[r] = __hip_atomic_load(dx_out + (size_t)i * step_stride +
-                                                       (size_t)(nd[r] >= 0 ? nd[r] : 0) * d + kcol,
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
                 f32x4 dxa = {0.f, 0.f, 0.f, 0.f};
                 // operands of hidden node ss: ga = G_i[ss][node = col][h = 4q..4q+3] (A of dX),
                 // zb[r] = Z_i[ss][h = 4q + r][16tc + col] (B of dX), gb[r] = G_i[ss][node = 4q + r][h = col] (A of dZ)
@@ -957,8 +943,17 @@ backward_pipe_kernel(const float *__restrict__ x, const float *__restrict__ z, c
                 const int k = 16 * tc + col;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (nd[r] >= 0 && k < d)
-                        dx_out[(size_t)i * step_stride + (size_t)nd[r] * d + k] = old[r] + dxa[r];
+                    if (nd[r] >= 0 && k < d) {
+                        // The first block of hidden graphs stores its share of dX, the later ones add theirs at
+                        // the L2 (an add without return value: nothing to wait for, where a load of the sum so far
+                        // cost a memory round trip per step).  Every element is owned by one lane, which issues
+                        // its store and its adds in block order, so the sum is formed in a fixed order.
+                        float *dst = dx_out + (size_t)i * step_stride + (size_t)nd[r] * d + k;
+                        if (hb > 0)
+                            (void)__hip_atomic_fetch_add(dst, dxa[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else
+                            *dst = dxa[r];
+                    }
                 }
             }
         }
