@@ -778,7 +778,13 @@ backward_pipe_kernel(const float *__restrict__ x, const float *__restrict__ z, c
         load_gid(t + 1);
     };
     // what prefetch(t) fetched goes to LDS: x rows -> xb, node ids -> tn[16], keep bits and scaled dK -> parity par
-    auto stage = [&](float *xb, int *tn, int par) {
+    int kb_node = 0;                                          // node of this thread's pair in the step last staged
+    auto draw_bits = [&](int par) {
+        if (DROP && kb_pair >= 0)
+            kbits[par * 256 + g_row(kb_pair >> 4) * 16 + (kb_pair & 15)] =
+                keep_bits(cfg, (uint32_t)kb_node, (uint32_t)(16 * hb_cur + (kb_pair >> 4)), n_calls);
+    };
+    auto stage = [&](float *xb, int *tn, int par, bool draw) {
 #pragma unroll
         for (int k = 0; k < kLoads; ++k) {
             const int idx = tid + k * kBwdBlock;
@@ -804,9 +810,8 @@ backward_pipe_kernel(const float *__restrict__ x, const float *__restrict__ z, c
             for (int i = 0; i < LT; ++i)
                 dks[((par * LT + i) * 16 + g_row(my_hl)) * 16 + my_slot] = pre_dk_ok ? pre_dk[i] * f : 0.f;
         }
-        if (DROP && kb_pair >= 0)
-            kbits[par * 256 + g_row(kb_pair >> 4) * 16 + (kb_pair & 15)] = keep_bits(cfg, (uint32_t)(st_node >= 0 ? st_node : 0),
-                                                   (uint32_t)(16 * hb_cur + (kb_pair >> 4)), n_calls);
+        kb_node = st_node >= 0 ? st_node : 0;
+        if (draw) draw_bits(par);
         // the graph id that came with this fetch is the one the next prefetch's dK loads use
         gc_cur = nxt_gid_ok ? nxt_gid : 0;
         gc_ok = nxt_gid_ok;
@@ -817,12 +822,8 @@ backward_pipe_kernel(const float *__restrict__ x, const float *__restrict__ z, c
     // group's parity at compile time), so that their LDS round trip passes under the previous group's MFMAs.
     auto phase_a = [&](const float *xb, int par, float *gbuf) {
         if (wave >= s) return;
-        float4 xv[LT][NT];                                    // B of the recompute: X_i[node = col][16tc + 4q ..]
-#pragma unroll
-        for (int i = 0; i < LT; ++i)
-#pragma unroll
-            for (int tc = 0; tc < NT; ++tc)
-                xv[i][tc] = *reinterpret_cast<const float4 *>(xb + i * 16 * ZS + roff<NT>(col, 16 * tc + 4 * q));
+        // Requests in the order of first use (LDS answers in order, and all eight wavefronts start the phase
+        // together): the first group's Z operands, then the x rows column group by column group.
         float4 za[2][LT];
         auto load_za = [&](int ss, int tc, float4 (&dst)[LT]) {
 #pragma unroll
@@ -830,6 +831,13 @@ backward_pipe_kernel(const float *__restrict__ x, const float *__restrict__ z, c
                 dst[i] = *reinterpret_cast<const float4 *>(zs + (i * s + ss) * 16 * ZS + roff<NT>(col, 16 * tc + 4 * q));
         };
         load_za(wave, 0, za[0]);
+        float4 xv[LT][NT];                                    // B of the recompute: X_i[node = col][16tc + 4q ..]
+#pragma unroll
+        for (int tc = 0; tc < NT; ++tc)
+#pragma unroll
+            for (int i = 0; i < LT; ++i)
+                xv[i][tc] = *reinterpret_cast<const float4 *>(xb + i * 16 * ZS + roff<NT>(col, 16 * tc + 4 * q));
+        __builtin_amdgcn_sched_barrier(0);                    // keep that order: the requests below are needed later
         unsigned long long kb[4] = {0, 0, 0, 0};
         if (DROP) {
 #pragma unroll
@@ -938,6 +946,24 @@ backward_pipe_kernel(const float *__restrict__ x, const float *__restrict__ z, c
                         dz[it][ss] = RWK_MFMA(o.gb[2], xq[2], dz[it][ss]);
                         dxa = RWK_MFMA(o.ga.w, o.zb[3], dxa);
                         dz[it][ss] = RWK_MFMA(o.gb[3], xq[3], dz[it][ss]);
+                        // scheduling: one or two of the next hidden node's nine operand requests after each MFMA
+                        // (all nine in a row after the first MFMA delayed the second one)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
                 }
                 const int k = 16 * tc + col;
@@ -960,6 +986,11 @@ backward_pipe_kernel(const float *__restrict__ x, const float *__restrict__ z, c
     };
 
     RWK_PSTAMP_DECL();
+    // With more than 8 hidden nodes the keep bits are drawn by both wavefronts of SIMDs 2 and 3.  Drawn at the same
+    // place of the step they would share the vector ALU while the matrix pipe idles (and the younger wavefront
+    // gets its turn only when the older one is through): wavefronts 6 and 7 draw theirs after phase B instead, so
+    // that on each of the two SIMDs one wavefront issues MFMAs while the other runs the generator.
+    const bool late_bits = DROP && s > kBwdWaves && __builtin_amdgcn_readfirstlane(wave) >= 6;
     // The blocks of 16 hidden graphs are taken one after the other by the same workgroup, so that their shares of
     // dX are added in block order by the lane that owns the element (no partial copies, no second launch).
     for (int hb = 0; hb < n_hb; ++hb) {
@@ -984,12 +1015,12 @@ backward_pipe_kernel(const float *__restrict__ x, const float *__restrict__ z, c
             float *tx = xb_; xb_ = xa_; xa_ = xs_; xs_ = tx;
             int *tn = nb_; nb_ = na_; na_ = ns_; ns_ = tn;
         };
-        stage(xs_, ns_, 0);                                   // step 0
+        stage(xs_, ns_, 0, true);                             // step 0
         rotate();                                             // step 0 is phase A's
         if (1 < stream_len) prefetch(1);
         __syncthreads();                                      // Z rows and step 0 staged
         phase_a(xa_, 0, gs);
-        if (1 < stream_len) stage(xs_, ns_, 1);               // step 1
+        if (1 < stream_len) stage(xs_, ns_, 1, true);         // step 1
         rotate();                                             // step 0 is phase B's, step 1 phase A's
         __syncthreads();
         if (2 < stream_len) prefetch(2);
@@ -998,9 +1029,10 @@ backward_pipe_kernel(const float *__restrict__ x, const float *__restrict__ z, c
             const int par = t & 1;
             if (t + 1 < stream_len) phase_a(xa_, par ^ 1, gs + (par ^ 1) * gs_buf);
             RWK_PSTAMP(0);
-            if (t + 2 < stream_len) stage(xs_, ns_, par);
+            if (t + 2 < stream_len) stage(xs_, ns_, par, !late_bits);
             RWK_PSTAMP(1);
             phase_b(xb_, nb_, gs + par * gs_buf, hb);
+            if (late_bits && t + 2 < stream_len) draw_bits(par);
             RWK_PSTAMP(2);
             rotate();
             __syncthreads();
