@@ -40,6 +40,10 @@ SIGNATURES = {
     "rwk_fused_backward": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_float, c_int,
                                    _P, _P, _P, _P, _P]),
     "rwk_fused_backward_workspace": (_I64, [_I64, _I64, _I64, _I64, _I64]),
+    "rwk_fused_keep_words": (_I64, [_I64, _I64, _I64, _I64, _I64]),
+    "rwk_fused_forward_bits": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_float, _P, _P, _P, _P]),
+    "rwk_fused_backward_bits": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_float, c_int,
+                                        _P, _P, _P, _P, _P, _P]),
     "rwk_fused_path": (c_int, [_I64, _I64, _I64, _I64]),
     "rwk_fused_stream_len": (_I64, [_I64, _I64, _I64, _I64, _I64, c_int]),
     "rwk_fused_keep_s_supported": (c_int, [_I64, _I64, _I64, _I64]),

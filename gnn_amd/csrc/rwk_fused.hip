@@ -566,9 +566,22 @@ int64_t rwk_fused_stream_len(int64_t n, int64_t d, int64_t h, int64_t s, int64_t
     return rwk_reg::stream_len(n, h, s, max_step, backward != 0);
 }
 
+int64_t rwk_fused_keep_words(int64_t n, int64_t d, int64_t h, int64_t s, int64_t max_step) {
+    if (n <= 0 || rwk_reg::supported(d, h, s, max_step)) return 0;
+    return rwk_mfma::keep_words(n, d, h, s, max_step);
+}
+
 int rwk_fused_forward(const float *x, const float *z, const int32_t *gid, const int32_t *perm, int64_t n,
                       int64_t d, int64_t h, int64_t s, int64_t max_step, int64_t stream_len, float drop_p,
                       const uint64_t *rng, float *k_partials, rwk_stream_t stream) {
+    return rwk_fused_forward_bits(x, z, gid, perm, n, d, h, s, max_step, stream_len, drop_p, rng, k_partials, nullptr,
+                                  stream);
+}
+
+int rwk_fused_forward_bits(const float *x, const float *z, const int32_t *gid, const int32_t *perm, int64_t n,
+                           int64_t d, int64_t h, int64_t s, int64_t max_step, int64_t stream_len, float drop_p,
+                           const uint64_t *rng, float *k_partials, uint64_t *keep_out, rwk_stream_t stream) {
+    if (keep_out != nullptr && rwk_fused_keep_words(n, d, h, s, max_step) == 0) return RWK_E_UNSUPPORTED;
     RWK_REQUIRE_PTR(x);
     RWK_REQUIRE_PTR(z);
     RWK_REQUIRE_PTR(gid);
@@ -590,6 +603,7 @@ int rwk_fused_forward(const float *x, const float *z, const int32_t *gid, const 
         r.n = (int)n; r.d = (int)d; r.h = (int)h; r.s = (int)s; r.max_step = (int)max_step;
         r.stream_len = (int)stream_len; r.drop = drop; r.rng = (const unsigned long long *)rng;
         r.stream = (hipStream_t)stream; r.k_partials = k_partials;
+        r.keep = (unsigned long long *)keep_out;
         rwk_drop_thresholds(drop_p, &r.t0, &r.t1);
         return rwk_mfma::forward(r);
     }
@@ -630,6 +644,16 @@ int rwk_fused_backward(const float *x, const float *z, const int32_t *gid, const
                        const float *counts_f32, int64_t n, int64_t d, int64_t h, int64_t s, int64_t max_step,
                        int64_t stream_len, float drop_p, int normalize, const uint64_t *rng, float *dx,
                        float *dz_partials, float *workspace, rwk_stream_t stream) {
+    return rwk_fused_backward_bits(x, z, gid, perm, d_k, counts_f32, n, d, h, s, max_step, stream_len, drop_p,
+                                   normalize, rng, dx, dz_partials, workspace, nullptr, stream);
+}
+
+int rwk_fused_backward_bits(const float *x, const float *z, const int32_t *gid, const int32_t *perm,
+                            const float *d_k, const float *counts_f32, int64_t n, int64_t d, int64_t h, int64_t s,
+                            int64_t max_step, int64_t stream_len, float drop_p, int normalize, const uint64_t *rng,
+                            float *dx, float *dz_partials, float *workspace, const uint64_t *keep_in,
+                            rwk_stream_t stream) {
+    if (keep_in != nullptr && rwk_fused_keep_words(n, d, h, s, max_step) == 0) return RWK_E_UNSUPPORTED;
     RWK_REQUIRE_PTR(x);
     RWK_REQUIRE_PTR(z);
     RWK_REQUIRE_PTR(gid);
@@ -658,6 +682,7 @@ int rwk_fused_backward(const float *x, const float *z, const int32_t *gid, const
         r.stream = (hipStream_t)stream; r.d_k = d_k; r.counts_f32 = counts_f32;
         r.scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f; r.normalize = normalize;
         r.dx = dx; r.dz_partials = dz_partials; r.dx_partials = workspace;
+        r.keep = (unsigned long long *)keep_in;
         if (rwk_mfma::dx_partials_size(n, d, h, max_step) > 0 && workspace == nullptr) return RWK_E_NULL;
         rwk_drop_thresholds(drop_p, &r.t0, &r.t1);
         return rwk_mfma::backward(r);

@@ -23,11 +23,16 @@ struct Args {
     float *dx;                     // (L,N,D)
     float *dx_partials;            // (ceil(H/16), L, N, D) workspace, needed when H > 16
     float *dz_partials;            // (backward_blocks, L, H, S, D)
+    // dropout keep bits per (node, hidden graph), N x H 64-bit words: written by the forward, read by the backward
+    // (NULL: the forward does not leave them / the backward runs the generator itself)
+    unsigned long long *keep;
 };
 
 bool supported(int64_t d, int64_t h, int64_t s, int64_t max_step);
 // workgroup columns of the backward launch = rows of dz_partials
 int64_t backward_blocks(int64_t n, int64_t stream_len);
+// 64-bit words of Args::keep when the backward for these sizes can take the forward's keep bits, else 0
+int64_t keep_words(int64_t n, int64_t d, int64_t h, int64_t s, int64_t max_step);
 // floats of dx_partials the backward needs (0 when H <= 16)
 int64_t dx_partials_size(int64_t n, int64_t d, int64_t h, int64_t max_step);
 // positions per stream that fill the chip in whole rounds of resident workgroups

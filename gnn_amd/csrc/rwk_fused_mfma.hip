@@ -188,7 +188,8 @@ template <int LT, int NT, bool DROP>
 __global__ void __launch_bounds__(kFwdBlock)
 forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const int *__restrict__ gid,
                const int *__restrict__ perm, int n, int d, int h, int s, int stream_len, int n_calls, uint32_t t0,
-               uint32_t t1, const unsigned long long *__restrict__ rng, float *__restrict__ k_partials) {
+               uint32_t t1, const unsigned long long *__restrict__ rng, float *__restrict__ k_partials,
+               unsigned long long *__restrict__ keep_out) {
     constexpr int ZS = row_stride<NT>();
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *zs = lds;
@@ -250,6 +251,12 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
         if (DROP) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) kb[r] = keep_bits(cfg, (uint32_t)node, (uint32_t)(hq0 + r), n_calls);
+            // left for the backward pass, which then does not run the generator again
+            if (keep_out != nullptr && valid) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (hq0 + r < h) keep_out[(size_t)node * h + hq0 + r] = kb[r];
+            }
         }
         float node_acc[LT][4];
 #pragma unroll
@@ -669,14 +676,14 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
 // memory counter the wait for those loads looks at.
 // ------------------------------------------------------------------------------------------------
 
-template <int LT, int NT, bool DROP, bool PERM>
+template <int LT, int NT, bool DROP, bool PERM, bool KEEP>
 __global__ void __launch_bounds__(kBwdBlock)
 backward_pipe_kernel(const float *__restrict__ x, const float *__restrict__ z, const int *__restrict__ gid,
                      const int *__restrict__ perm, const float *__restrict__ d_k,
                      const float *__restrict__ counts_f32, int n, int d, int h, int s, int stream_len, int n_calls,
                      float scale, int normalize, uint32_t t0, uint32_t t1,
                      const unsigned long long *__restrict__ rng, int n_hb, float *__restrict__ dx_out,
-                     float *__restrict__ dz_partials) {
+                     float *__restrict__ dz_partials, const unsigned long long *__restrict__ keep_in) {
     constexpr int DPAD = 16 * NT, ZS = row_stride<NT>();
     constexpr int ITEMS = LT * NT, IPW = (ITEMS + kBwdWaves - 1) / kBwdWaves;
     constexpr int XB = LT * 16 * ZS;                          // floats of one x-row buffer
@@ -695,7 +702,7 @@ backward_pipe_kernel(const float *__restrict__ x, const float *__restrict__ z, c
     const int lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, col = lane & 15;
     DropCfg cfg;
-    if (DROP) cfg = load_cfg(rng, t0, t1);
+    if (DROP && !KEEP) cfg = load_cfg(rng, t0, t1);
     const int lh = LT * h;
     const size_t step_stride = (size_t)n * d;
     int hq0 = 4 * q;
@@ -736,6 +743,7 @@ backward_pipe_kernel(const float *__restrict__ x, const float *__restrict__ z, c
     int my_hqc = my_hq < h ? my_hq : h - 1;
     int pre_node = 0;
     bool pre_node_ok = false;
+    unsigned long long pre_kb = 0;
     float pre_dk[LT], pre_cnt = 1.f;
     bool pre_dk_ok = false;
     int nxt_gid = 0;
@@ -770,6 +778,8 @@ backward_pipe_kernel(const float *__restrict__ x, const float *__restrict__ z, c
         pre_node_ok = t < my_count;
         const int pc = pre_node_ok ? my_first + t : 0;
         pre_node = PERM ? perm[pc] : pc;
+        // keep bits the forward pass left (pair (my_slot, my_hl), threads 0..255)
+        if (KEEP && tid < 256) pre_kb = keep_in[(size_t)pre_node * h + my_hqc];
         const int gc = gc_cur;                                // graph of my_slot at step t (fetched a step ago)
         pre_dk_ok = gc_ok && my_hq < h && tid < 256;
         if (normalize) pre_cnt = counts_f32[gc];
@@ -811,7 +821,11 @@ backward_pipe_kernel(const float *__restrict__ x, const float *__restrict__ z, c
                 dks[((par * LT + i) * 16 + g_row(my_hl)) * 16 + my_slot] = pre_dk_ok ? pre_dk[i] * f : 0.f;
         }
         kb_node = st_node >= 0 ? st_node : 0;
-        if (draw) draw_bits(par);
+        if (KEEP) {
+            if (tid < 256) kbits[par * 256 + g_row(my_hl) * 16 + my_slot] = pre_node_ok && my_hq < h ? pre_kb : 0ull;
+        } else if (draw) {
+            draw_bits(par);
+        }
         // the graph id that came with this fetch is the one the next prefetch's dK loads use
         gc_cur = nxt_gid_ok ? nxt_gid : 0;
         gc_ok = nxt_gid_ok;
@@ -990,7 +1004,7 @@ backward_pipe_kernel(const float *__restrict__ x, const float *__restrict__ z, c
     // place of the step they would share the vector ALU while the matrix pipe idles (and the younger wavefront
     // gets its turn only when the older one is through): wavefronts 6 and 7 draw theirs after phase B instead, so
     // that on each of the two SIMDs one wavefront issues MFMAs while the other runs the generator.
-    const bool late_bits = DROP && s > kBwdWaves && __builtin_amdgcn_readfirstlane(wave) >= 6;
+    const bool late_bits = DROP && !KEEP && s > kBwdWaves && __builtin_amdgcn_readfirstlane(wave) >= 6;
     // The blocks of 16 hidden graphs are taken one after the other by the same workgroup, so that their shares of
     // dX are added in block order by the lane that owns the element (no partial copies, no second launch).
     for (int hb = 0; hb < n_hb; ++hb) {
@@ -1090,7 +1104,7 @@ int launch_fwd(const Args &a) {
             if (e != hipSuccess) return (int)e;                                                                 \
         }                                                                                                       \
         hipLaunchKernelGGL(kern, grid, dim3(kFwdBlock), lds, a.stream, a.x, a.z, a.gid, a.perm, a.n, a.d, a.h, a.s, \
-                           a.stream_len, n_calls, a.t0, a.t1, a.rng, a.k_partials);                             \
+                           a.stream_len, n_calls, a.t0, a.t1, a.rng, a.k_partials, a.keep);                     \
     }
     if (a.drop) RWK_F(true) else RWK_F(false)
 #undef RWK_F
@@ -1106,6 +1120,20 @@ inline size_t bwd_pipe_lds(int l, int s, int nt) {
 // the pipelined kernel when its buffers fit the 160 KB of LDS (with a little room left for the runtime)
 inline bool pipelined(int l, int s, int nt) { return bwd_pipe_lds(l, s, nt) + 256 <= 160 * 1024; }
 
+template <int LT, int NT, bool DROPV, bool KEEP>
+int launch_pipe(const Args &a, dim3 grid, size_t lds, int n_calls, int hb) {
+    auto kern = a.perm ? backward_pipe_kernel<LT, NT, DROPV, true, KEEP> : backward_pipe_kernel<LT, NT, DROPV, false, KEEP>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(kBwdBlock), lds, a.stream, a.x, a.z, a.gid, a.perm, a.d_k, a.counts_f32, a.n,
+                       a.d, a.h, a.s, a.stream_len, n_calls, a.scale, a.normalize, a.t0, a.t1, a.rng, hb, a.dx,
+                       a.dz_partials, (const unsigned long long *)a.keep);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
 template <int LT, int NT>
 int launch_bwd(const Args &a) {
     const int hb = (a.h + 15) / 16;
@@ -1116,17 +1144,20 @@ int launch_bwd(const Args &a) {
     float *dx_target = a.dx;
 #define RWK_B(DROPV)                                                                                            \
     {                                                                                                           \
-        auto kern = pipe ? (a.perm ? backward_pipe_kernel<LT, NT, DROPV, true>                                  \
-                                   : backward_pipe_kernel<LT, NT, DROPV, false>)                                \
-                         : (a.perm ? backward_kernel<LT, NT, DROPV, true> : backward_kernel<LT, NT, DROPV, false>); \
-        if (lds > 64 * 1024) {                                                                                  \
-            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                               (int)lds);                                                       \
-            if (e != hipSuccess) return (int)e;                                                                 \
+        if (pipe) {                                                                                             \
+            return (DROPV && a.keep != nullptr) ? launch_pipe<LT, NT, DROPV, DROPV>(a, grid, lds, n_calls, hb)  \
+                                                : launch_pipe<LT, NT, DROPV, false>(a, grid, lds, n_calls, hb); \
+        } else {                                                                                                \
+            auto kern = a.perm ? backward_kernel<LT, NT, DROPV, true> : backward_kernel<LT, NT, DROPV, false>;  \
+            if (lds > 64 * 1024) {                                                                              \
+                hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                   (int)lds);                                                   \
+                if (e != hipSuccess) return (int)e;                                                             \
+            }                                                                                                   \
+            hipLaunchKernelGGL(kern, grid, dim3(kBwdBlock), lds, a.stream, a.x, a.z, a.gid, a.perm, a.d_k,      \
+                               a.counts_f32, a.n, a.d, a.h, a.s, a.stream_len, n_calls, a.scale, a.normalize, a.t0, \
+                               a.t1, a.rng, hb, dx_target, a.dz_partials);                                      \
         }                                                                                                       \
-        hipLaunchKernelGGL(kern, grid, dim3(kBwdBlock), lds, a.stream, a.x, a.z, a.gid, a.perm, a.d_k, a.counts_f32, \
-                           a.n, a.d, a.h, a.s, a.stream_len, n_calls, a.scale, a.normalize, a.t0, a.t1, a.rng,  \
-                           hb, dx_target, a.dz_partials);                                                           \
     }
     if (a.drop) RWK_B(true) else RWK_B(false)
 #undef RWK_B
@@ -1166,6 +1197,13 @@ bool supported(int64_t d, int64_t h, int64_t s, int64_t max_step) {
 }
 
 int64_t backward_blocks(int64_t n, int64_t stream_len) { return rwk_ceil_div(rwk_ceil_div(n, stream_len), 16); }
+
+int64_t keep_words(int64_t n, int64_t d, int64_t h, int64_t s, int64_t max_step) {
+    if (!supported(d, h, s, max_step)) return 0;
+    int nt = nt_of((int)d);
+    if (nt == 3) nt = 4;
+    return pipelined((int)max_step, (int)s, nt) ? n * h : 0;  // the unpipelined backward draws its own bits
+}
 
 int64_t dx_partials_size(int64_t n, int64_t d, int64_t h, int64_t max_step) {
     (void)n; (void)d; (void)h; (void)max_step;

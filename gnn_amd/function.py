@@ -35,6 +35,9 @@ FUSED_STEP_LAUNCHES = True
 #: gradient elements of the graphs it walks), the head's parameter-gradient sums into the last launch; False keeps
 #: the head's own launch (tests compare the two)
 FOLD_HEAD_FINISH = True
+# matrix-core path: the forward's dropout keep bits travel to the backward in memory (8 bytes per (node, hidden
+# graph)) instead of being drawn a second time
+KEEP_BITS_HANDOVER = True
 
 def choose_stream_len(n_nodes: int, hidden_dim: int, n_hidden: int, size_hidden: int, max_step: int,
                       backward: bool = False) -> int:
@@ -137,9 +140,16 @@ class _RWKernelLayer(torch.autograd.Function):
             plan = _plan(lib, st, d, n_hidden, s, steps)
             stream_len = plan["stream_len"]
             k_partials = torch.empty(plan["k_slots"], dtype=torch.float32, device=dev)
-            _lib.check(lib.rwk_fused_forward(xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm),
-                                             n, d, n_hidden, s, steps, stream_len, drop, _lib.ptr(rng_used),
-                                             k_partials.data_ptr(), stream), "rwk_fused_forward")
+            # matrix-core path, training with dropout: the forward leaves its keep bits for the backward
+            keep = None
+            if drop and KEEP_BITS_HANDOVER and any(ctx.needs_input_grad):
+                words = lib.rwk_fused_keep_words(n, d, n_hidden, s, steps)
+                if words > 0:
+                    keep = torch.empty(words, dtype=torch.int64, device=dev)
+            _lib.check(lib.rwk_fused_forward_bits(xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm),
+                                                  n, d, n_hidden, s, steps, stream_len, drop, _lib.ptr(rng_used),
+                                                  k_partials.data_ptr(), _lib.ptr(keep), stream),
+                       "rwk_fused_forward_bits")
             k = torch.empty((g, steps * n_hidden), dtype=torch.float32, device=dev)
             if handoff is not None and FUSED_STEP_LAUNCHES and steps * n_hidden <= 256:
                 # the head's batch statistics (and its draw of the generator state) ride in the K reduction
@@ -166,14 +176,14 @@ class _RWKernelLayer(torch.autograd.Function):
         ctx.cfg = (steps, bool(normalize), drop, projected)
         ctx.fuse_step = fuse_step
         ctx.handoff = handoff
-        ctx.save_for_backward(xs, z, ah, adj_hidden_c, rng_used, inp_c if projected else None, w_c)
+        ctx.save_for_backward(xs, z, ah, adj_hidden_c, rng_used, inp_c if projected else None, w_c, keep)
         return k
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, d_k):
         lib = _lib.load()
-        xs, z, ah, adj_hidden_c, rng_used, feats, w_c = ctx.saved_tensors
+        xs, z, ah, adj_hidden_c, rng_used, feats, w_c, keep = ctx.saved_tensors
         st: GraphStructure = ctx.st
         steps, normalize, drop, projected = ctx.cfg
         _, n_hidden, s, d = z.shape
@@ -202,11 +212,12 @@ class _RWKernelLayer(torch.autograd.Function):
                     fold["partials"].shape[0], fold["partials"].shape[1], fold["o_gamma"], fold["d_loss"].data_ptr(),
                     st.n_graphs, stream), "rwk_fused_backward_bn")
             else:
-                _lib.check(lib.rwk_fused_backward(xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm),
-                                                  d_k.data_ptr(), st.counts_f32.data_ptr(), n, d, n_hidden, s, steps,
-                                                  stream_len, drop, int(normalize), _lib.ptr(rng_used),
-                                                  dx.data_ptr(), dz_partials.data_ptr(), _lib.ptr(ws), stream),
-                           "rwk_fused_backward")
+                _lib.check(lib.rwk_fused_backward_bits(xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(),
+                                                       _lib.ptr(st.perm), d_k.data_ptr(), st.counts_f32.data_ptr(), n, d,
+                                                       n_hidden, s, steps, stream_len, drop, int(normalize),
+                                                       _lib.ptr(rng_used), dx.data_ptr(), dz_partials.data_ptr(),
+                                                       _lib.ptr(ws), _lib.ptr(keep), stream),
+                           "rwk_fused_backward_bits")
             # dZ partials: first level here (to at most 32 rows), the rest inside rwk_hidden_backward.  It is
             # independent of the SpMM chain and rides in the first SpMM's launch when there is one.
             dz, dz_rows, job = dz_partials, n_part, None

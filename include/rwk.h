@@ -186,6 +186,25 @@ int rwk_fused_forward(const float *x, const float *z, const int32_t *gid, const 
                       int64_t stream_len, float drop_p, const uint64_t *rng, float *k_partials,
                       rwk_stream_t stream);
 
+/* Dropout keep bits handed from the forward to the backward pass (rwgnn2/model.py:64 applies one mask in the
+ * forward; autograd replays it in the backward).  Without the hand-over the backward runs the counter-based generator
+ * again (same bits, no memory); on the matrix-core path (hidden_dim 8..64) the generator costs as much vector-ALU
+ * time in the backward as in the forward, and vector-ALU time is not hidden behind fp32 MFMAs.
+ * rwk_fused_keep_words: 64-bit words of the buffer (n * h) when the hand-over is built for these sizes, else 0.
+ * rwk_fused_forward_bits / rwk_fused_backward_bits: as rwk_fused_forward / rwk_fused_backward with that buffer
+ * (keep_out / keep_in; NULL = the plain entry point); RWK_E_UNSUPPORTED when rwk_fused_keep_words is 0 and a buffer
+ * is passed.  Same results bit for bit. */
+int64_t rwk_fused_keep_words(int64_t n, int64_t d, int64_t h, int64_t s, int64_t max_step);
+int rwk_fused_forward_bits(const float *x, const float *z, const int32_t *gid, const int32_t *perm,
+                           int64_t n, int64_t d, int64_t h, int64_t s, int64_t max_step,
+                           int64_t stream_len, float drop_p, const uint64_t *rng, float *k_partials,
+                           uint64_t *keep_out, rwk_stream_t stream);
+int rwk_fused_backward_bits(const float *x, const float *z, const int32_t *gid, const int32_t *perm,
+                            const float *d_k, const float *counts_f32, int64_t n, int64_t d, int64_t h,
+                            int64_t s, int64_t max_step, int64_t stream_len, float drop_p,
+                            int normalize, const uint64_t *rng, float *dx, float *dz_partials,
+                            float *workspace, const uint64_t *keep_in, rwk_stream_t stream);
+
 int rwk_fused_reduce(const float *k_partials, const int32_t *seg_ptr, const float *counts_f32,
                      int64_t n_graphs, int64_t h, int64_t max_step, int64_t stream_len,
                      float drop_p, int normalize, float *k, rwk_stream_t stream);

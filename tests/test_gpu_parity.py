@@ -251,6 +251,34 @@ def test_backward_is_bitwise_reproducible(name, dev):
             assert torch.equal(a, b)
 
 
+def test_keep_bits_from_the_forward_equal_a_second_draw(dev, monkeypatch):
+    """Matrix-core path: the backward pass takes the dropout keep bits the forward left in memory; the result is
+    the same bits as with the generator run a second time (the other widths always draw again)."""
+    from gnn_amd import _lib, get_structure, rw_kernel_layer
+    from gnn_amd import function as fn
+    c = GoldenCase("wide_h64_s10_d64")
+    hp = c.hp
+    m = _model_for(c, dev, train=True)
+    adj, feats, gi, _ = c.torch_inputs(dev)
+    st = get_structure(adj, gi)
+    h, s, steps, d = hp["hidden_graphs"], hp["size_hidden_graphs"], hp["max_step"], hp["hidden_dim"]
+    assert _lib.load().rwk_fused_keep_words(c.n_nodes, d, h, s, steps) == c.n_nodes * h
+    dk = torch.from_numpy(c["dk"]).to(dev)
+    runs = []
+    for on in (True, False):
+        monkeypatch.setattr(fn, "KEEP_BITS_HANDOVER", on)
+        rng = torch.tensor([0x5EED5EED, 17], dtype=torch.int64, device=dev)
+        pre = m.fc(feats).detach().requires_grad_(True)
+        adj_h = m.adj_hidden.detach().clone().requires_grad_(True)
+        z = m.features_hidden.detach().clone().requires_grad_(True)
+        k = rw_kernel_layer(pre, adj_h, z, st, steps, bool(hp["normalize"]), 0.3, rng)
+        k.backward(dk)
+        runs.append((k.detach().clone(), pre.grad.clone(), adj_h.grad.clone(), z.grad.clone()))
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    assert float(runs[0][1].abs().sum()) > 0
+
+
 @pytest.mark.parametrize("name,p", [("mutag_b0", 0.2), ("directed3_dups", 0.5), ("powerlawish_d32_step4", 0.1),
                                     ("wide_h64_s10_d64", 0.3), ("unsorted_indicator", 0.25)])
 def test_dropout_mask_replay(name, p, dev):
