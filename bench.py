@@ -129,15 +129,24 @@ def time_kernels(batch_t, hp, budget_ms=150.0, only=None):
     def run_spmm():
         st.spmm(xs[0], y)
 
+    # the training step's form of the two launches: on the matrix-core path the forward leaves its dropout keep bits
+    # in memory and the backward reads them (gnn_amd/function.py); elsewhere keep is None = the plain entry points
+    keep_n = lib.rwk_fused_keep_words(n, d, h, s, steps) if p > 0 else 0
+    keep = torch.empty(keep_n, dtype=torch.int64, device=dev) if keep_n else None
+
     def run_fwd():
-        _lib.check(lib.rwk_fused_forward(xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm), n, d, h,
-                                         s, steps, stream_len, p, rng.data_ptr(), k_part.data_ptr(), stream), "fwd")
+        _lib.check(lib.rwk_fused_forward_bits(xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm), n, d,
+                                              h, s, steps, stream_len, p, rng.data_ptr(), k_part.data_ptr(),
+                                              _lib.ptr(keep), stream), "fwd")
+
+    if keep is not None:
+        run_fwd()                                             # the backward's timing loop reads what this one left
 
     def run_bwd():
-        _lib.check(lib.rwk_fused_backward(xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm),
-                                          dk.data_ptr(), st.counts_f32.data_ptr(), n, d, h, s, steps, stream_len_b, p,
-                                          0, rng.data_ptr(), dx.data_ptr(), dz_part.data_ptr(), _lib.ptr(ws), stream),
-                   "bwd")
+        _lib.check(lib.rwk_fused_backward_bits(xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm),
+                                               dk.data_ptr(), st.counts_f32.data_ptr(), n, d, h, s, steps,
+                                               stream_len_b, p, 0, rng.data_ptr(), dx.data_ptr(), dz_part.data_ptr(),
+                                               _lib.ptr(ws), _lib.ptr(keep), stream), "bwd")
 
     lh = steps * h
     # algorithmic HBM bytes per launch (fp32 and int32 are 4 bytes):
@@ -146,8 +155,8 @@ def time_kernels(batch_t, hp, budget_ms=150.0, only=None):
     #   backward:  X read + dX written, graph ids, dK, the per-workgroup dZ partial rows written
     bytes_ = {
         "spmm_csr": st.spmm_bytes(d),
-        "fused_forward": steps * n * d * 4 + n * 4 + (n_streams + g) * lh * 4 + steps * h * s * d * 4,
-        "fused_backward": 2 * steps * n * d * 4 + n * 4 + g * lh * 4 + n_part * steps * h * s * d * 4,
+        "fused_forward": steps * n * d * 4 + n * 4 + (n_streams + g) * lh * 4 + steps * h * s * d * 4 + keep_n * 8,
+        "fused_backward": 2 * steps * n * d * 4 + n * 4 + g * lh * 4 + n_part * steps * h * s * d * 4 + keep_n * 8,
     }
     # algorithmic flops (the roofline's numerator): forward (L+1) contractions of 2 H S D flops per node (zx and the
     # L products T_i) plus 3 element-wise flops per (step, hidden node, node); backward twice the forward's
