@@ -23,7 +23,8 @@ struct Args {
     float *dx;                     // (L,N,D)
     float *dx_partials;            // (ceil(H/16), L, N, D) workspace, needed when H > 16
     float *dz_partials;            // (backward_blocks, L, H, S, D)
-    // dropout keep bits per (node, hidden graph), N x H 64-bit words: written by the forward, read by the backward
+    // dropout keep bits per (node, hidden graph), N x H words of 32 bits (S * L <= 32) or 64 bits: written by the
+    // forward, read by the backward
     // (NULL: the forward does not leave them / the backward runs the generator itself)
     unsigned long long *keep;
 };

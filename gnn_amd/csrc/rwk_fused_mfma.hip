@@ -252,10 +252,17 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
 #pragma unroll
             for (int r = 0; r < 4; ++r) kb[r] = keep_bits(cfg, (uint32_t)node, (uint32_t)(hq0 + r), n_calls);
             // left for the backward pass, which then does not run the generator again
+            // (32-bit words when the S * L samples of a pair fit them)
             if (keep_out != nullptr && valid) {
+                const bool k32 = s * LT <= 32;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (hq0 + r < h) keep_out[(size_t)node * h + hq0 + r] = kb[r];
+                for (int r = 0; r < 4; ++r) {
+                    if (hq0 + r < h) {
+                        const size_t idx = (size_t)node * h + hq0 + r;
+                        if (k32) reinterpret_cast<uint32_t *>(keep_out)[idx] = (uint32_t)kb[r];
+                        else keep_out[idx] = kb[r];
+                    }
+                }
             }
         }
         float node_acc[LT][4];
@@ -779,7 +786,11 @@ backward_pipe_kernel(const float *__restrict__ x, const float *__restrict__ z, c
         const int pc = pre_node_ok ? my_first + t : 0;
         pre_node = PERM ? perm[pc] : pc;
         // keep bits the forward pass left (pair (my_slot, my_hl), threads 0..255)
-        if (KEEP && tid < 256) pre_kb = keep_in[(size_t)pre_node * h + my_hqc];
+        if (KEEP && tid < 256) {
+            const size_t idx = (size_t)pre_node * h + my_hqc;
+            if (s * LT <= 32) pre_kb = reinterpret_cast<const uint32_t *>(keep_in)[idx];
+            else pre_kb = keep_in[idx];
+        }
         const int gc = gc_cur;                                // graph of my_slot at step t (fetched a step ago)
         pre_dk_ok = gc_ok && my_hq < h && tid < 256;
         if (normalize) pre_cnt = counts_f32[gc];
@@ -1202,7 +1213,8 @@ int64_t keep_words(int64_t n, int64_t d, int64_t h, int64_t s, int64_t max_step)
     if (!supported(d, h, s, max_step)) return 0;
     int nt = nt_of((int)d);
     if (nt == 3) nt = 4;
-    return pipelined((int)max_step, (int)s, nt) ? n * h : 0;  // the unpipelined backward draws its own bits
+    if (!pipelined((int)max_step, (int)s, nt)) return 0;      // the unpipelined backward draws its own bits
+    return s * max_step <= 32 ? (n * h + 1) / 2 : n * h;      // one 32-bit or one 64-bit word per pair
 }
 
 int64_t dx_partials_size(int64_t n, int64_t d, int64_t h, int64_t max_step) {

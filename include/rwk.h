@@ -190,7 +190,8 @@ int rwk_fused_forward(const float *x, const float *z, const int32_t *gid, const 
  * forward; autograd replays it in the backward).  Without the hand-over the backward runs the counter-based generator
  * again (same bits, no memory); on the matrix-core path (hidden_dim 8..64) the generator costs as much vector-ALU
  * time in the backward as in the forward, and vector-ALU time is not hidden behind fp32 MFMAs.
- * rwk_fused_keep_words: 64-bit words of the buffer (n * h) when the hand-over is built for these sizes, else 0.
+ * rwk_fused_keep_words: 64-bit words of the buffer when the hand-over is built for these sizes, else 0 (one 32-bit
+ * word per (node, hidden graph) when s * max_step <= 32, i.e. (n * h + 1) / 2, else one 64-bit word, n * h).
  * rwk_fused_forward_bits / rwk_fused_backward_bits: as rwk_fused_forward / rwk_fused_backward with that buffer
  * (keep_out / keep_in; NULL = the plain entry point); RWK_E_UNSUPPORTED when rwk_fused_keep_words is 0 and a buffer
  * is passed.  Same results bit for bit. */

@@ -262,7 +262,8 @@ def test_keep_bits_from_the_forward_equal_a_second_draw(dev, monkeypatch):
     adj, feats, gi, _ = c.torch_inputs(dev)
     st = get_structure(adj, gi)
     h, s, steps, d = hp["hidden_graphs"], hp["size_hidden_graphs"], hp["max_step"], hp["hidden_dim"]
-    assert _lib.load().rwk_fused_keep_words(c.n_nodes, d, h, s, steps) == c.n_nodes * h
+    words = c.n_nodes * h if s * steps > 32 else (c.n_nodes * h + 1) // 2
+    assert _lib.load().rwk_fused_keep_words(c.n_nodes, d, h, s, steps) == words
     dk = torch.from_numpy(c["dk"]).to(dev)
     runs = []
     for on in (True, False):
