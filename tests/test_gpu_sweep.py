@@ -17,7 +17,9 @@ SWEEP = [(16, 3, 4, 1, False), (16, 4, 3, 2, True), (7, 5, 4, 3, False), (16, 6,
          (16, 10, 4, 3, True), (33, 5, 4, 2, False), (64, 6, 1, 2, False), (3, 3, 4, 4, True), (16, 5, 4, 4, False),
          (16, 5, 8, 2, False), (20, 3, 16, 3, True), (48, 10, 32, 2, False), (64, 12, 64, 1, True),
          (9, 7, 12, 2, False), (16, 5, 20, 4, True), (5, 2, 8, 3, False), (16, 11, 4, 2, False), (2, 9, 5, 2, True),
-         (40, 4, 24, 2, False), (16, 9, 8, 4, False)]       # the last one: 36 mask samples per (node, hidden graph)
+         (40, 4, 24, 2, False),
+         (16, 9, 8, 4, False),                             # 36 mask samples per (node, hidden graph): 64-bit keep words
+         (33, 12, 64, 2, True)]                            # matrix cores, unpipelined backward, three blocks of hidden graphs
 
 
 @pytest.fixture(scope="module")
