@@ -26,6 +26,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -73,6 +74,20 @@ def parse_args():
     ap.add_argument("--dp-shape", type=int, default=0,
                     help="one GPU only: time the step in the shape a rank of an N-rank run executes (two graphs and "
                          "the collective's slot between them, no process group) to see what the shape itself costs")
+    ap.add_argument("--stream", action="store_true",
+                    help="never-repeating batches: a pool of --pool-batches distinct batches of the configuration as "
+                         "one device-resident data set, each batch assembled (DeviceDataset.batch, structure included) "
+                         "inside the timed region right before its step, on a side stream under the previous step "
+                         "(gnn_amd.trainer.StreamTrainer); steps are launched eagerly")
+    ap.add_argument("--pool-batches", type=int, default=31,
+                    help="--stream: distinct batches per pass (31 x 4096 = 127 k graphs: one GPU's share of the "
+                         "1 M-graph stream of BASELINE.json configs[2])")
+    ap.add_argument("--distinct-batches", type=int, default=0,
+                    help="time an epoch over this many different resident batches of the configuration replayed as one "
+                         "HIP graph (gnn_amd.trainer.EpochTrainer; 16 x 23 MB leaves the 256 MB Infinity Cache) "
+                         "instead of one resident batch")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="default run: skip the extra measurements (distinct batches, stream_h64 stream, drop-in)")
     return ap.parse_args()
 
 
@@ -281,6 +296,95 @@ def drop_in_step(batch_t, hp, dev, steps=300, warmup=30):
                     "torch.optim.Adam, per-parameter gradients (host-bound)"}
 
 
+def _new_model(hp, dev, seed=1234):
+    from gnn_amd import RW_NN
+    torch.manual_seed(0)
+    model = RW_NN(hp["input_dim"], hp["max_step"], hp["hidden_graphs"], hp["size_hidden_graphs"], hp["hidden_dim"],
+                  hp["penultimate_dim"], hp["normalize"], hp["n_classes"], hp["dropout"], dev).to(dev)
+    model.train()
+    model.seed_dropout(seed)
+    return model
+
+
+def _timed(run, steps):
+    """Wall-clock and device time of ``run(steps)`` between two synchronisations."""
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    run(steps)
+    ev1.record()
+    while not ev1.query():
+        pass
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, ev0.elapsed_time(ev1)
+
+
+def distinct_batches_epoch(config, hp, dev, k, epochs=8, seed0=100):
+    """The reference's epoch loop (rwgnn2/main.py:103-106) over ``k`` DIFFERENT resident batches of the configuration,
+    replayed as one HIP graph per epoch (gnn_amd.trainer.EpochTrainer): every step meets a batch the caches have not
+    seen for k - 1 steps."""
+    from gnn_amd.synth import config_batch
+    from gnn_amd.trainer import EpochTrainer
+    batches = [config_batch(config, seed=seed0 + i).to_torch(dev) for i in range(k)]
+    tr = EpochTrainer(_new_model(hp, dev), batches)
+    tr.capture_epoch()
+    tr.run_epoch()
+    elapsed, dev_ms = _timed(lambda n: [tr.run_epoch() for _ in range(n)], epochs)
+    graphs = sum(int(b[3].numel()) for b in batches)
+    nbytes = sum(b[1].numel() * 4 + b[0]._values().numel() * 20 + b[2].numel() * 8 for b in batches)
+    return {"batches": k, "epochs": epochs, "ms_per_step": round(elapsed / (epochs * k) * 1e3, 4),
+            "device_ms_per_step": round(dev_ms / (epochs * k), 4),
+            "graphs_per_s": round(graphs * epochs / elapsed, 1), "input_MB": round(nbytes / 1e6, 1),
+            "final_loss": round(float(tr.epoch_losses[-1]), 5),
+            "what": "EpochTrainer: one HIP-graph replay per epoch over %d different resident batches" % k}
+
+
+class StreamBench:
+    """A pool of distinct batches of a configuration as one device-resident data set, streamed batch by batch."""
+
+    def __init__(self, config, hp, dev, pool_batches, seed, optimizer="flat", world=1, sync_before_all_reduce=False):
+        from gnn_amd.data import DeviceDataset
+        from gnn_amd.synth import config_batch
+        from gnn_amd.trainer import StreamTrainer
+        whole = config_batch(config, seed=seed, scale=pool_batches)
+        self.per_batch = whole.n_graphs // pool_batches
+        self.ds = DeviceDataset.from_batch(whole, dev)
+        self.id_lists = [np.arange(i * self.per_batch, (i + 1) * self.per_batch) for i in range(pool_batches)]
+        shapes = [self.ds.batch_shape(ids) for ids in self.id_lists]
+        self.nodes = sum(s[0] for s in shapes)
+        self.tr = StreamTrainer(_new_model(hp, dev, seed), self.ds, self.per_batch, max(s[0] for s in shapes),
+                                max(s[1] for s in shapes), depth=3, world=world, optimizer=optimizer,
+                                sync_before_all_reduce=sync_before_all_reduce)
+        self.cursor = 0
+
+    def run(self, steps):
+        """``steps`` training steps, each on the next batch of the pool (whole passes, then the rest)."""
+        pool = len(self.id_lists)
+        while steps > 0:
+            take = min(steps, pool - self.cursor)
+            self.tr.run_pass(self.id_lists[self.cursor:self.cursor + take], keep_losses=False)
+            self.cursor = (self.cursor + take) % pool
+            steps -= take
+
+    def describe(self):
+        return ("pool of %d distinct batches x %d graphs (%d nodes) resident as one data set; every batch assembled "
+                "inside the timed region (one upload + one launch on a side stream, structure included), steps "
+                "launched eagerly" % (len(self.id_lists), self.per_batch, self.nodes))
+
+
+def stream_extra(config, dev, pool_batches=31, steps=62, warmup=8):
+    """The streamed pass of a configuration as an extra key of the default line."""
+    from gnn_amd.synth import CONFIGS
+    hp = dict(CONFIGS[config]["hp"])
+    sb = StreamBench(config, hp, dev, pool_batches, seed=4321)
+    sb.run(warmup)
+    elapsed, dev_ms = _timed(sb.run, steps)
+    return {"config": config, "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "device_ms_per_step": round(dev_ms / steps, 4),
+            "graphs_per_s": round(sb.per_batch * steps / elapsed, 1), "what": sb.describe()}
+
+
 def cpu_baseline(batch, hp, n_graphs, budget_s=20.0):
     """Forward + backward (train mode, dropout on) of the PyTorch-CPU port on the first n_graphs graphs."""
     from oracle import rwnn_torch_port as P
@@ -399,34 +503,57 @@ def main():
     if batch.n_graphs < 2:
         raise SystemExit("%s is a batch of one graph: BatchNorm1d cannot train on it (model.py:68 raises in the "
                          "reference too); run it with --kernels-only" % args.config)
-    torch.manual_seed(0)
-    model = RW_NN(hp["input_dim"], hp["max_step"], hp["hidden_graphs"], hp["size_hidden_graphs"], hp["hidden_dim"],
-                  hp["penultimate_dim"], hp["normalize"], hp["n_classes"], hp["dropout"], dev).to(dev)
-    model.train()
-    model.seed_dropout(1234 + rank)
-    broadcast_parameters(model)
     shape_world = args.dp_shape if (world == 1 and args.dp_shape > 1) else world
     capture_collective = args.capture_allreduce or os.environ.get("RWK_CAPTURE_ALLREDUCE", "0") == "1"
-    tr = Trainer(model, batch_t, shape_world, args.optimizer, sync_before_all_reduce=backend != "nccl",
-                 capture_collective=capture_collective and world > 1)
     launch = args.mode
     run_steps = None
-    if args.mode == "graph":
-        try:
-            spg = args.steps_per_graph if (shape_world == 1 and args.steps_per_graph > 1) else 1
-            tr.capture(steps_per_graph=spg)
-            step = tr.step_graph
-            if tr.multi_k > 1:
-                run_steps = tr.run_steps
-                launch = "graph (%d steps per replay)" % tr.multi_k
-        except Exception as exc:        # a capture that the runtime refuses must not cost the whole measurement
-            print(f"[bench] HIP-graph capture failed ({type(exc).__name__}: {exc}); launching eagerly",
-                  file=sys.stderr, flush=True)
-            torch.cuda.synchronize()
-            launch = "eager (capture failed)"
-            step = tr.step_eager
+    stream_bench = None
+    graphs_per_step = batch.n_graphs
+    if args.stream:
+        # never-repeating batches: assembly inside the timed region, eager steps (StreamTrainer)
+        stream_bench = StreamBench(args.config, hp, dev, args.pool_batches, seed=1 + rank, optimizer=args.optimizer,
+                                   world=world, sync_before_all_reduce=backend != "nccl")
+        model, tr = stream_bench.tr.model, stream_bench.tr
+        broadcast_parameters(model)
+        run_steps = stream_bench.run
+        graphs_per_step = stream_bench.per_batch
+        launch = "eager, streamed: " + stream_bench.describe()
+    elif args.distinct_batches > 1:
+        if world > 1:
+            raise SystemExit("--distinct-batches is a single-process measurement")
+        from gnn_amd.trainer import EpochTrainer
+        k = args.distinct_batches
+        batches = [batch_t] + [config_batch(args.config, seed=100 + i, scale=args.scale).to_torch(dev)
+                               for i in range(1, k)]
+        model = _new_model(hp, dev, 1234)
+        tr = EpochTrainer(model, batches, optimizer=args.optimizer)
+        tr.capture_epoch()
+        args.steps = max(k, args.steps // k * k)           # whole epochs: one replay each
+        args.warmup = max(k, args.warmup // k * k)
+        run_steps = lambda n: [tr.run_epoch() for _ in range(n // k)]   # noqa: E731
+        graphs_per_step = sum(int(b[3].numel()) for b in batches) / k
+        launch = "graph (one replay per epoch of %d different resident batches, EpochTrainer)" % k
     else:
-        step = tr.step_eager
+        model = _new_model(hp, dev, 1234 + rank)
+        broadcast_parameters(model)
+        tr = Trainer(model, batch_t, shape_world, args.optimizer, sync_before_all_reduce=backend != "nccl",
+                     capture_collective=capture_collective and world > 1)
+        if args.mode == "graph":
+            try:
+                spg = args.steps_per_graph if (shape_world == 1 and args.steps_per_graph > 1) else 1
+                tr.capture(steps_per_graph=spg)
+                step = tr.step_graph
+                if tr.multi_k > 1:
+                    run_steps = tr.run_steps
+                    launch = "graph (%d steps per replay)" % tr.multi_k
+            except Exception as exc:        # a capture that the runtime refuses must not cost the whole measurement
+                print(f"[bench] HIP-graph capture failed ({type(exc).__name__}: {exc}); launching eagerly",
+                      file=sys.stderr, flush=True)
+                torch.cuda.synchronize()
+                launch = "eager (capture failed)"
+                step = tr.step_eager
+        else:
+            step = tr.step_eager
 
     # The per-kernel timings of the roofline entry run before the timed steps, not after: they keep the device busy
     # for some 25 ms, and the step needs ~10 ms of load to reach its steady duration (the first 80 replays after an
@@ -461,14 +588,14 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     device_ms = ev0.elapsed_time(ev1)
-    n_graphs_total = batch.n_graphs
+    n_graphs_total = graphs_per_step
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([batch.n_graphs], dtype=torch.float64, device=dev)
+        c = torch.tensor([graphs_per_step], dtype=torch.float64, device=dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        n_graphs_total = int(c.item())
+        n_graphs_total = float(c.item())
     loss = float(tr.loss.item())
     # where a data-parallel step spends its time (every rank runs it: the collective needs them all)
     phases = tr.phase_times() if (launch == "graph" and shape_world > 1) else None
@@ -513,6 +640,14 @@ def main():
             result["roofline"] = roofline_of(kern, dom, traffic.get(dom, {}).get("hbm_bytes"))
         if world == 1 and not args.no_kernel_timing:
             result["drop_in_eager"] = drop_in_step(batch_t, hp, dev)
+        plain = not (args.stream or args.distinct_batches > 1 or args.no_extras or args.no_kernel_timing)
+        if world == 1 and plain and args.config == "proteins1024":
+            # what no resident-batch figure covers: batches that change every step
+            try:
+                result["distinct_batches"] = distinct_batches_epoch(args.config, hp, dev, 16)
+                result["stream_h64_stream"] = stream_extra("stream_h64", dev)
+            except Exception as exc:                      # the extras never cost the headline
+                result["extras_error"] = "%s: %s" % (type(exc).__name__, str(exc)[:300])
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(batch, hp, args.cpu_sample_graphs)
         print(json.dumps(result), flush=True)

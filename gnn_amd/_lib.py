@@ -26,6 +26,8 @@ SIGNATURES = {
     "rwk_indicator_inspect": (c_int, [_P, _I64, _P, _P]),
     "rwk_segments_build": (c_int, [_P, _I64, _I64, _P, _P, _P, _P, _P, _P]),
     "rwk_batch_gather_coo": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    "rwk_batch_build": (c_int, [_P, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                _P, _P, _P, _P, _P]),
     "rwk_spmm_csr": (c_int, [_P, _P, _P, _I64, _I64, _P, _P, c_int, c_int32, _P, _I64, c_int32, _P]),
     "rwk_csr_compact": (c_int, [_P, _P, _P, _I64, _P, _P, _P]),
     "rwk_spmm_csr_compact": (c_int, [_P, _P, _P, _I64, _I64, _P, _P, c_int, _P]),

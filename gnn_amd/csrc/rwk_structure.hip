@@ -48,6 +48,10 @@ __global__ void csr_count_asymmetric_kernel(const int32_t *__restrict__ crow, co
     int bad = 0;
     for (int32_t j = crow[r]; j < crow[r + 1]; ++j) {
         const int32_t c = col[j];
+        if (c < 0 || (int64_t)c >= n) {      // the caller may not have read the range check's verdict yet
+            ++bad;
+            continue;
+        }
         int32_t lo = crow[c], hi = crow[c + 1];
         while (lo < hi) {
             const int32_t mid = (lo + hi) >> 1;
@@ -70,7 +74,13 @@ __global__ void indicator_inspect_kernel(const int64_t *__restrict__ gi, int64_t
         const int32_t g32 = g > 0x7FFFFFFF ? 0x7FFFFFFF : (int32_t)g;
         atomicMax(&flags[1], g32);
     }
-    if (p > 0 && g < gi[p - 1]) atomicAdd(&flags[0], 1);
+    if (p > 0) {
+        const int64_t prev = gi[p - 1];
+        if (g < prev) atomicAdd(&flags[0], 1);
+        if (g > prev + 1) atomicAdd(&flags[3], 1);
+    } else if (g != 0) {
+        atomicAdd(&flags[3], 1);
+    }
 }
 
 __global__ void segments_build_kernel(const int64_t *__restrict__ ids, int64_t n, int64_t n_graphs,
@@ -114,9 +124,127 @@ batch_gather_coo_kernel(const int64_t *__restrict__ ds_row_ptr, const int32_t *_
     }
 }
 
+// One launch from a list of graphs of the data set to everything a training step needs of the batch: the COO list
+// (the reference's interface), features, graph_indicator, labels, and the CSR / compact columns / segment arrays
+// the kernels run on.  A node finds its graph by binary search in the batch's node offsets (the host holds the
+// per-graph sizes, so the offsets, n and nnz are known without asking the device); inside a graph the data set's
+// own row pointer is already the prefix sum a CSR needs.
+struct BatchBuildArgs {
+    const int64_t *ds_row_ptr;
+    const int32_t *ds_col;
+    const float *ds_val;
+    const float *ds_feat;
+    const int64_t *ds_y;
+    const int64_t *table;      // (4, b+1): new node start, data-set node start, new entry start, data-set graph id
+    int64_t b, n, nnz, n_feat;
+    int64_t *coo_rows, *coo_cols;
+    float *coo_vals;
+    float *feat;
+    int64_t *gi, *y;
+    int32_t *crow, *col;
+    float *val;
+    int16_t *col16;
+    int32_t *gid, *seg_ptr;
+    int64_t *counts;
+    float *counts_f32;
+    int64_t node_blocks;
+};
+
+// last g in [0, b) with start[g] <= v
+__device__ inline int64_t graph_of_node(const int64_t *__restrict__ start, int64_t b, int64_t v) {
+    int64_t lo = 0, hi = b;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (start[mid] <= v) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(kBlock) batch_build_kernel(const BatchBuildArgs a) {
+    const int64_t *__restrict__ new_start = a.table;
+    const int64_t *__restrict__ old_start = a.table + (a.b + 1);
+    const int64_t *__restrict__ new_entry = a.table + 2 * (a.b + 1);
+    const int64_t *__restrict__ graph_id = a.table + 3 * (a.b + 1);
+    if ((int64_t)blockIdx.x >= a.node_blocks) {
+        // wide feature rows: one element per thread, coalesced along the row
+        const int64_t e = ((int64_t)blockIdx.x - a.node_blocks) * kBlock + threadIdx.x;
+        if (e >= a.n * a.n_feat) return;
+        const int64_t v = e / a.n_feat, k = e - v * a.n_feat;
+        const int64_t g = graph_of_node(new_start, a.b, v);
+        a.feat[e] = a.ds_feat[(old_start[g] + (v - new_start[g])) * a.n_feat + k];
+        return;
+    }
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t < a.b) {
+        const int64_t s0 = new_start[t], s1 = new_start[t + 1];
+        if (a.seg_ptr) {
+            a.seg_ptr[t] = (int32_t)s0;
+            if (t == a.b - 1) a.seg_ptr[a.b] = (int32_t)s1;
+        }
+        if (a.counts) a.counts[t] = s1 - s0;
+        if (a.counts_f32) a.counts_f32[t] = (float)(s1 - s0);
+        if (a.y) a.y[t] = a.ds_y[graph_id[t]];
+    }
+    if (t >= a.n) return;
+    const int64_t g = graph_of_node(new_start, a.b, t);
+    const int64_t first_old = old_start[g];
+    const int64_t src = first_old + (t - new_start[g]);
+    const int64_t beg = a.ds_row_ptr[src], end = a.ds_row_ptr[src + 1];
+    int64_t o = new_entry[g] + (beg - a.ds_row_ptr[first_old]);
+    const int64_t delta = new_start[g] - first_old;
+    if (a.crow) {
+        a.crow[t] = (int32_t)o;
+        if (t == a.n - 1) a.crow[a.n] = (int32_t)(o + (end - beg));
+    }
+    if (a.gid) a.gid[t] = (int32_t)g;
+    if (a.gi) a.gi[t] = g;
+    if (a.feat && a.n_feat <= 4)
+        for (int64_t k = 0; k < a.n_feat; ++k) a.feat[t * a.n_feat + k] = a.ds_feat[src * a.n_feat + k];
+    const int64_t base = t & ~(int64_t)255;
+    for (int64_t e = beg; e < end; ++e, ++o) {
+        const int64_t c = (int64_t)a.ds_col[e] + delta;
+        const float w = a.ds_val[e];
+        if (a.coo_rows) {
+            a.coo_rows[o] = t;
+            a.coo_cols[o] = c;
+            a.coo_vals[o] = w;
+        }
+        if (a.col) a.col[o] = (int32_t)c;
+        if (a.val) a.val[o] = w;
+        if (a.col16) a.col16[o] = (int16_t)(c - base);
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int rwk_batch_build(const int64_t *ds_row_ptr, const int32_t *ds_col, const float *ds_val, const float *ds_feat,
+                    int64_t n_feat, const int64_t *ds_y, const int64_t *table, int64_t b, int64_t n, int64_t nnz,
+                    int64_t *coo_rows, int64_t *coo_cols, float *coo_vals, float *feat, int64_t *gi, int64_t *y,
+                    int32_t *crow, int32_t *col, float *val, int16_t *col16, int32_t *gid, int32_t *seg_ptr,
+                    int64_t *counts, float *counts_f32, rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(ds_row_ptr);
+    RWK_REQUIRE_PTR(table);
+    if (b <= 0 || n <= 0 || b > n || !fits_i32(n) || !fits_i32(nnz) || n_feat < 0) return RWK_E_SIZE;
+    if (nnz > 0) {
+        RWK_REQUIRE_PTR(ds_col);
+        RWK_REQUIRE_PTR(ds_val);
+    }
+    if (feat != nullptr) RWK_REQUIRE_PTR(ds_feat);
+    if (y != nullptr) RWK_REQUIRE_PTR(ds_y);
+    if ((coo_rows == nullptr) != (coo_cols == nullptr) || (coo_rows == nullptr) != (coo_vals == nullptr))
+        return RWK_E_NULL;
+    BatchBuildArgs a{ds_row_ptr, ds_col, ds_val, ds_feat, ds_y, table, b, n, nnz, n_feat, coo_rows, coo_cols,
+                     coo_vals, feat, gi, y, crow, col, val, col16, gid, seg_ptr, counts, counts_f32, 0};
+    a.node_blocks = rwk_ceil_div(n, kBlock);
+    const int64_t feat_blocks = (feat != nullptr && n_feat > 4) ? rwk_ceil_div(n * n_feat, kBlock) : 0;
+    if (a.node_blocks + feat_blocks >= 0x7FFFFFFFll) return RWK_E_SIZE;
+    hipLaunchKernelGGL(batch_build_kernel, dim3((unsigned)(a.node_blocks + feat_blocks)), dim3(kBlock), 0,
+                       (hipStream_t)stream, a);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
 
 int rwk_batch_gather_coo(const int64_t *ds_row_ptr, const int32_t *ds_col, const float *ds_val,
                          const int64_t *src_node, const int64_t *col_delta, const int64_t *out_ptr, int64_t n,

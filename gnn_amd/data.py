@@ -53,13 +53,22 @@ def load_data(ds_name: str, use_node_labels: bool, root: str = "datasets"):
     return adj, features, class_labels
 
 
+class _Slot:
+    """Preallocated output buffers of one batch (:meth:`DeviceDataset.make_slots`)."""
+    __slots__ = ("idx", "vals", "feats", "gi", "y", "crow", "col", "val", "col16", "gid", "seg_ptr", "counts",
+                 "counts_f32", "cap")
+
+
 class DeviceDataset:
-    """All graphs of a data set on the device as one block-diagonal CSR, ready for batch gathers."""
+    """All graphs of a data set on the device as one block-diagonal CSR, ready for batch gathers.
+
+    The per-graph sizes stay on the host as well, so the shape of a batch (nodes, stored entries, offsets of its
+    graphs, largest row) is known without asking the device: :meth:`batch` is one small upload and ONE launch
+    (``rwk_batch_build``) that writes the reference's four tensors and the structure the kernels need (int32 CSR,
+    16-bit columns, graph ids, segment pointers, counts), never waits for the device, and so can run on a side
+    stream under the previous training step."""
 
     def __init__(self, adj: Sequence, features: Sequence, y, device):
-        dev = torch.device(device)
-        if dev.type != "cuda":
-            raise RuntimeError("gnn_amd assembles batches on HIP devices only (no CPU fallback)")
         sizes = np.array([m.shape[0] for m in adj], dtype=np.int64)
         node_ptr = np.concatenate([[0], np.cumsum(sizes)])
         row_ptr = [np.zeros(1, dtype=np.int64)]
@@ -75,43 +84,174 @@ class DeviceDataset:
             vals.append(m.data.astype(np.float32))      # utils.py:39 casts the batch to float32
             nnz += int(m.indptr[-1])
         feats = np.vstack([np.asarray(f, dtype=np.float64) for f in features]).astype(np.float32)
-        self.device = dev
-        self.n_graphs = len(adj)
-        self.node_ptr = torch.from_numpy(node_ptr).to(dev)
-        self.row_ptr = torch.from_numpy(np.concatenate(row_ptr)).to(dev)
-        self.col = torch.from_numpy(np.concatenate(cols).astype(np.int32) if cols else np.zeros(0, np.int32)).to(dev)
-        self.val = torch.from_numpy(np.concatenate(vals) if vals else np.zeros(0, np.float32)).to(dev)
-        self.features = torch.from_numpy(feats).to(dev)
-        self.y = torch.from_numpy(np.asarray(y, dtype=np.int64)).to(dev)
+        self._init_arrays(node_ptr, np.concatenate(row_ptr),
+                          np.concatenate(cols).astype(np.int32) if cols else np.zeros(0, np.int32),
+                          np.concatenate(vals) if vals else np.zeros(0, np.float32), feats,
+                          np.asarray(y, dtype=np.int64), device)
 
-    def batch(self, graph_ids):
-        """(adj, features, graph_indicator, y) of the batch made of these graphs, in this order."""
+    @classmethod
+    def from_arrays(cls, node_ptr, row_ptr, col, val, features, y, device) -> "DeviceDataset":
+        """From the block-diagonal CSR itself: ``node_ptr`` (G+1) first node of every graph, ``row_ptr`` (N+1),
+        ``col`` (data-set node ids, rows column-sorted without duplicates), ``val``, ``features`` (N, F), ``y`` (G)."""
+        ds = cls.__new__(cls)
+        ds._init_arrays(np.asarray(node_ptr, dtype=np.int64), np.asarray(row_ptr, dtype=np.int64),
+                        np.asarray(col, dtype=np.int32), np.asarray(val, dtype=np.float32),
+                        np.asarray(features, dtype=np.float32), np.asarray(y, dtype=np.int64), device)
+        return ds
+
+    @classmethod
+    def from_batch(cls, batch, device) -> "DeviceDataset":
+        """The graphs of a ``gnn_amd.synth.Batch`` (row-major sorted COO, block-diagonal) as a data set."""
+        n = batch.n_nodes
+        row_ptr = np.concatenate([[0], np.cumsum(np.bincount(batch.indices[0], minlength=n))])
+        node_ptr = np.concatenate([[0], np.cumsum(batch.sizes)])
+        return cls.from_arrays(node_ptr, row_ptr, batch.indices[1], batch.values, batch.features, batch.y, device)
+
+    def _init_arrays(self, node_ptr, row_ptr, col, val, feats, y, device):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("gnn_amd assembles batches on HIP devices only (no CPU fallback)")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        n_all = int(node_ptr[-1])
+        if row_ptr.size != n_all + 1 or feats.shape[0] != n_all or y.size != node_ptr.size - 1:
+            raise ValueError("inconsistent data set arrays")
+        self.device = dev
+        self.n_graphs = int(node_ptr.size - 1)
+        self.n_feat = int(feats.shape[1])
+        # host-side shape of every graph: what batch() needs to size and place a batch without a device read
+        self.node_ptr_h = node_ptr
+        self.edge_ptr_h = row_ptr[node_ptr]
+        deg = np.diff(row_ptr)
+        nonempty = np.diff(node_ptr) > 0
+        self.graph_max_degree_h = np.zeros(self.n_graphs, dtype=np.int64)
+        if n_all and nonempty.any():
+            self.graph_max_degree_h[nonempty] = np.maximum.reduceat(deg, node_ptr[:-1][nonempty])
+        self.unit_values = bool(np.all(val == np.float32(1.0)))
+        self.node_ptr = torch.from_numpy(node_ptr).to(dev)
+        self.row_ptr = torch.from_numpy(row_ptr).to(dev)
+        self.col = torch.from_numpy(col).to(dev)
+        self.val = torch.from_numpy(val).to(dev)
+        self.features = torch.from_numpy(np.ascontiguousarray(feats)).to(dev)
+        self.y = torch.from_numpy(y).to(dev)
+        # A == A^T bit for bit, once per data set (a batch of symmetric graphs is symmetric): one device read here
+        self.symmetric = True
+        if col.size:
+            lib = _lib.load()
+            if n_all >= 2 ** 31 - 1 or col.size >= 2 ** 31 - 1:
+                raise ValueError("data set too large for 32-bit row pointers")
+            with torch.cuda.device(dev):
+                flag = torch.zeros(1, dtype=torch.int32, device=dev)
+                crow32 = self.row_ptr.to(torch.int32)
+                _lib.check(lib.rwk_csr_count_asymmetric(crow32.data_ptr(), self.col.data_ptr(), self.val.data_ptr(),
+                                                        n_all, flag.data_ptr(), _lib.current_stream(dev)),
+                           "rwk_csr_count_asymmetric")
+                self.symmetric = int(flag.item()) == 0
+
+    # ------------------------------------------------------------------------------------
+    def batch_shape(self, graph_ids):
+        """(nodes, stored entries) of the batch made of these graphs, from the host-side sizes."""
+        ids = np.asarray(graph_ids, dtype=np.int64)
+        return (int((self.node_ptr_h[ids + 1] - self.node_ptr_h[ids]).sum()),
+                int((self.edge_ptr_h[ids + 1] - self.edge_ptr_h[ids]).sum()))
+
+    def make_slots(self, count: int, max_graphs: int, max_nodes: int, max_nnz: int):
+        """``count`` sets of preallocated batch buffers for :meth:`batch` (``slot=``): a loop that streams batches
+        through them allocates nothing per batch.  The caller orders the reuse of a slot after the last use of the
+        batch it held (``gnn_amd.trainer.StreamTrainer`` does)."""
+        dev = self.device
+        slots = []
+        for _ in range(count):
+            s = _Slot()
+            s.cap = (int(max_graphs), int(max_nodes), int(max_nnz))
+            s.idx = torch.empty(2 * max(max_nnz, 1), dtype=torch.int64, device=dev)
+            s.vals = torch.empty(max(max_nnz, 1), dtype=torch.float32, device=dev)
+            s.feats = torch.empty(max_nodes * max(self.n_feat, 1), dtype=torch.float32, device=dev)
+            s.gi = torch.empty(max_nodes, dtype=torch.int64, device=dev)
+            s.y = torch.empty(max_graphs, dtype=torch.int64, device=dev)
+            s.crow = torch.empty(max_nodes + 1, dtype=torch.int32, device=dev)
+            s.col = torch.empty(max(max_nnz, 1), dtype=torch.int32, device=dev)
+            s.val = torch.empty(max(max_nnz, 1), dtype=torch.float32, device=dev)
+            s.col16 = torch.empty(max(max_nnz, 1), dtype=torch.int16, device=dev)
+            s.gid = torch.empty(max_nodes, dtype=torch.int32, device=dev)
+            s.seg_ptr = torch.empty(max_graphs + 1, dtype=torch.int32, device=dev)
+            s.counts = torch.empty(max_graphs, dtype=torch.int64, device=dev)
+            s.counts_f32 = torch.empty(max_graphs, dtype=torch.float32, device=dev)
+            slots.append(s)
+        return slots
+
+    def batch(self, graph_ids, slot: "_Slot" = None):
+        """(adj, features, graph_indicator, y) of the batch made of these graphs, in this order (the loop body of
+        ``utils.py:60-83``), with the batch's structure already in the structure cache: ``get_structure(adj,
+        graph_indicator)`` - what ``RW_NN.forward`` calls first - finds it without building or reading anything.
+        No device-to-host read, one upload (4 x (graphs + 1) int64), one launch on the current stream."""
+        from .structure import GraphStructure, register_structure
         lib = _lib.load()
         dev = self.device
+        ids = np.asarray(graph_ids, dtype=np.int64).reshape(-1)
+        b = int(ids.size)
+        if b == 0:
+            raise ValueError("empty batch")
+        if ids.min() < 0 or ids.max() >= self.n_graphs:
+            raise IndexError("graph id outside the data set")
+        table = np.empty((4, b + 1), dtype=np.int64)
+        table[0, 0] = table[2, 0] = 0
+        np.cumsum(self.node_ptr_h[ids + 1] - self.node_ptr_h[ids], out=table[0, 1:])
+        table[1, :b] = self.node_ptr_h[ids]
+        np.cumsum(self.edge_ptr_h[ids + 1] - self.edge_ptr_h[ids], out=table[2, 1:])
+        table[3, :b] = ids
+        table[1, b] = table[3, b] = 0
+        n, nnz = int(table[0, b]), int(table[2, b])
+        if n == 0:
+            raise ValueError("empty batch")
+        max_graph = int(np.diff(table[0]).max())
+        max_degree = int(self.graph_max_degree_h[ids].max())
+        fits16 = max_graph + 255 <= 32767          # |column - first row of the row's 256-row block| within int16
+        f = self.n_feat
         with torch.cuda.device(dev):
-            ids = torch.as_tensor(np.asarray(graph_ids, dtype=np.int64), device=dev)
-            b = ids.numel()
-            old_start = self.node_ptr[ids]
-            sizes = self.node_ptr[ids + 1] - old_start
-            new_start = torch.cumsum(sizes, 0) - sizes
-            n = int(sizes.sum().item())
-            gi = torch.repeat_interleave(torch.arange(b, device=dev, dtype=torch.int64), sizes, output_size=n)
-            delta_g = new_start - old_start
-            col_delta = delta_g[gi]
-            src_node = torch.arange(n, device=dev, dtype=torch.int64) - col_delta
-            deg = self.row_ptr[src_node + 1] - self.row_ptr[src_node]
-            out_ptr = torch.cumsum(deg, 0) - deg
-            nnz = int(deg.sum().item())
-            rows = torch.empty(nnz, dtype=torch.int64, device=dev)
-            cols = torch.empty(nnz, dtype=torch.int64, device=dev)
-            vals = torch.empty(nnz, dtype=torch.float32, device=dev)
-            if n > 0:
-                _lib.check(lib.rwk_batch_gather_coo(self.row_ptr.data_ptr(), _lib.ptr(self.col), _lib.ptr(self.val),
-                                                    src_node.data_ptr(), col_delta.data_ptr(), out_ptr.data_ptr(), n,
-                                                    _lib.ptr(rows), _lib.ptr(cols), _lib.ptr(vals),
-                                                    _lib.current_stream(dev)), "rwk_batch_gather_coo")
-            adj = torch.sparse_coo_tensor(torch.stack([rows, cols]), vals, (n, n))
-            return adj, self.features[src_node], gi, self.y[ids]
+            table_d = torch.from_numpy(table).pin_memory().to(dev, non_blocking=True)
+            if slot is None:
+                idx = torch.empty((2, nnz), dtype=torch.int64, device=dev)
+                vals = torch.empty(nnz, dtype=torch.float32, device=dev)
+                feats = torch.empty((n, f), dtype=torch.float32, device=dev)
+                gi = torch.empty(n, dtype=torch.int64, device=dev)
+                yy = torch.empty(b, dtype=torch.int64, device=dev)
+                crow = torch.empty(n + 1, dtype=torch.int32, device=dev)
+                col = torch.empty(nnz, dtype=torch.int32, device=dev)
+                val = torch.empty(nnz, dtype=torch.float32, device=dev)
+                col16 = torch.empty(nnz, dtype=torch.int16, device=dev) if (fits16 and nnz) else None
+                gid = torch.empty(n, dtype=torch.int32, device=dev)
+                seg_ptr = torch.empty(b + 1, dtype=torch.int32, device=dev)
+                counts = torch.empty(b, dtype=torch.int64, device=dev)
+                counts_f32 = torch.empty(b, dtype=torch.float32, device=dev)
+            else:
+                cb, cn, ce = slot.cap
+                if b > cb or n > cn or nnz > ce:
+                    raise ValueError(f"batch of {b} graphs, {n} nodes, {nnz} entries exceeds the slot ({cb}, {cn}, {ce})")
+                idx = slot.idx[:2 * nnz].view(2, nnz)
+                vals = slot.vals[:nnz]
+                feats = slot.feats[:n * f].view(n, f)
+                gi, yy = slot.gi[:n], slot.y[:b]
+                crow, col, val = slot.crow[:n + 1], slot.col[:nnz], slot.val[:nnz]
+                col16 = slot.col16[:nnz] if (fits16 and nnz) else None
+                gid, seg_ptr = slot.gid[:n], slot.seg_ptr[:b + 1]
+                counts, counts_f32 = slot.counts[:b], slot.counts_f32[:b]
+            nz = nnz > 0
+            _lib.check(lib.rwk_batch_build(
+                self.row_ptr.data_ptr(), _lib.ptr(self.col), _lib.ptr(self.val), self.features.data_ptr(), f,
+                self.y.data_ptr(), table_d.data_ptr(), b, n, nnz,
+                idx[0].data_ptr() if nz else None, idx[1].data_ptr() if nz else None, vals.data_ptr() if nz else None,
+                feats.data_ptr() if f else None, gi.data_ptr(), yy.data_ptr(), crow.data_ptr(),
+                col.data_ptr() if nz else None, val.data_ptr() if nz else None, _lib.ptr(col16), gid.data_ptr(),
+                seg_ptr.data_ptr(), counts.data_ptr(), counts_f32.data_ptr(), _lib.current_stream(dev)),
+                "rwk_batch_build")
+            adj = torch.sparse_coo_tensor(idx, vals, (n, n), check_invariants=False)
+            if self.symmetric:
+                st = GraphStructure.from_parts(dev, n, nnz, b, crow, col, val, col16, self.unit_values, max_degree,
+                                               gid, seg_ptr, counts, counts_f32)
+                register_structure(adj, gi, st)
+            # an asymmetric data set needs the transposed CSR as well: get_structure builds it on first use
+            return adj, feats, gi, yy
 
 
 def generate_batches(adj, features, y, batch_size, device, shuffle=False):

@@ -17,7 +17,8 @@ import torch
 
 from . import _lib
 
-__all__ = ["GraphStructure", "get_structure", "clear_structure_cache", "spmm_schedule", "use_tile_kernel"]
+__all__ = ["GraphStructure", "get_structure", "register_structure", "clear_structure_cache", "spmm_schedule",
+           "use_tile_kernel"]
 
 
 class _Csr:
@@ -118,29 +119,42 @@ class GraphStructure:
             cols = idx[1].contiguous()
             gi = graph_indicator.contiguous()
             nnz_in = rows.numel()
-            flags = torch.zeros(8, dtype=torch.int32, device=dev)
+            # Every decision that needs a look at the data is launched first and read back ONCE: the inspections of
+            # the COO list and of graph_indicator, and - on the assumption they will confirm (row-major sorted COO,
+            # as generate_batches builds it) - the CSR, its compact columns, the symmetry test and the largest row.
+            #   [0] unsorted COO entries  [1] indices out of range  [4] unsorted ids  [5] max id  [6] negative ids
+            #   [7] gaps in sorted ids    [8] columns beyond 16 bits  [9] values != 1  [10] asymmetric entries
+            #   [11] largest row
+            flags = torch.zeros(16, dtype=torch.int32, device=dev)
             _lib.check(lib.rwk_coo_inspect(_lib.ptr(rows), _lib.ptr(cols), nnz_in, n, flags.data_ptr(), stream),
                        "rwk_coo_inspect")
             _lib.check(lib.rwk_indicator_inspect(gi.data_ptr(), n, flags[4:].data_ptr(), stream),
                        "rwk_indicator_inspect")
-            f = flags.cpu().tolist()                      # host sync #1 (once per batch)
+            csr = st._csr_from_sorted(lib, rows, cols, vals, n, stream, flags[8:], flags[10:], flags[11:])
+            f = flags.cpu().tolist()                      # the one host read-back of a build (once per batch)
             unsorted_coo, out_of_range = f[0], f[1]
-            gi_unsorted, gi_max, gi_negative = f[4], f[5], f[6]
+            gi_unsorted, gi_max, gi_negative, gi_gaps = f[4], f[5], f[6], f[7]
             if out_of_range:
                 raise IndexError("adj has indices outside [0, N)")
             if gi_negative:
                 raise IndexError("graph_indicator has negative ids")
             n_graphs = gi_max + 1
-            if n_graphs > n:
+            if n_graphs > n or (not gi_unsorted and gi_gaps):
                 raise IndexError("graph_indicator ids must cover 0..G-1 without gaps")
             if unsorted_coo:
                 # rare path (hand-built inputs): let torch sort and sum duplicates exactly as
-                # torch.spmm's own coalesce would
+                # torch.spmm's own coalesce would, and build again (a second read-back)
                 co = adj.coalesce()
                 idx = co.indices()
                 rows, cols, vals = idx[0].contiguous(), idx[1].contiguous(), co.values().contiguous()
-            st.csr = st._csr_from_sorted(lib, rows, cols, vals, n, stream)
+                flags = torch.zeros(16, dtype=torch.int32, device=dev)
+                csr = st._csr_from_sorted(lib, rows, cols, vals, n, stream, flags[8:], flags[10:], flags[11:])
+                f = flags.cpu().tolist()
+            st.csr = csr
             st.nnz = int(rows.numel())
+            st._apply_flags(csr, f[8], f[9])
+            st.symmetric = f[10] == 0
+            st._schedule(csr, f[11])
 
             if gi_unsorted:
                 ids_sorted, order = torch.sort(gi, stable=True)
@@ -152,35 +166,49 @@ class GraphStructure:
             st.seg_ptr = torch.empty(n_graphs + 1, dtype=torch.int32, device=dev)
             st.counts = torch.empty(n_graphs, dtype=torch.int64, device=dev)
             st.counts_f32 = torch.empty(n_graphs, dtype=torch.float32, device=dev)
-            flags2 = torch.zeros(4, dtype=torch.int32, device=dev)
+            empty = torch.zeros(1, dtype=torch.int32, device=dev)
             _lib.check(lib.rwk_segments_build(ids_sorted.data_ptr(), n, n_graphs, st.gid.data_ptr(),
                                               st.seg_ptr.data_ptr(), st.counts.data_ptr(),
-                                              st.counts_f32.data_ptr(), flags2[1:].data_ptr(), stream),
+                                              st.counts_f32.data_ptr(), empty.data_ptr(), stream),
                        "rwk_segments_build")
-            if st.nnz:
-                _lib.check(lib.rwk_csr_count_asymmetric(st.csr.crow.data_ptr(), st.csr.col.data_ptr(),
-                                                        st.csr.val.data_ptr(), n, flags2.data_ptr(), stream),
-                           "rwk_csr_count_asymmetric")
-                deg = st.csr.crow[1:] - st.csr.crow[:-1]
-                flags2[2] = deg.max()
-            f2 = flags2.cpu().tolist()                    # host sync #2
-            if f2[1]:
+            # sorted ids: "no gaps" was already read with the flags; unsorted ids (rare) ask the segment kernel
+            if gi_unsorted and int(empty.item()):
                 raise IndexError("graph_indicator ids must cover 0..G-1 without gaps")
-            st.symmetric = f2[0] == 0
-            st._schedule(st.csr, f2[2])
             if st.symmetric:
                 st.csr_t = st.csr
             else:
                 t = torch.sparse_coo_tensor(torch.stack([cols, rows]), vals, (n, n)).coalesce()
                 ti = t.indices()
+                tflags = torch.zeros(16, dtype=torch.int32, device=dev)
                 st.csr_t = st._csr_from_sorted(lib, ti[0].contiguous(), ti[1].contiguous(),
-                                               t.values().contiguous(), n, stream)
-                tdeg = st.csr_t.crow[1:] - st.csr_t.crow[:-1]
-                st._schedule(st.csr_t, int(tdeg.max().item()))
+                                               t.values().contiguous(), n, stream, tflags[8:], None, tflags[11:])
+                tf = tflags.cpu().tolist()
+                st._apply_flags(st.csr_t, tf[8], tf[9])
+                st._schedule(st.csr_t, tf[11])
         return st
 
     @staticmethod
-    def _csr_from_sorted(lib, rows, cols, vals, n, stream) -> _Csr:
+    def from_parts(device, n, nnz, n_graphs, crow, col, val, col16, unit_values, max_degree, gid, seg_ptr, counts,
+                   counts_f32) -> "GraphStructure":
+        """A structure from arrays the caller already holds (``gnn_amd.data.DeviceDataset.batch`` writes them in its
+        one launch and knows the host-side facts from the data set): a symmetric matrix with sorted graph ids.  No
+        launch and no device read here, unless the matrix has rows long enough for the packed kernel's long-row
+        list."""
+        st = GraphStructure()
+        st.device, st.n, st.nnz, st.n_graphs = device, int(n), int(nnz), int(n_graphs)
+        csr = _Csr(crow, col, val)
+        csr.col16 = col16
+        csr.unit_values = bool(unit_values)
+        st.csr = st.csr_t = csr
+        st.symmetric = True
+        st.gid, st.seg_ptr, st.counts, st.counts_f32 = gid, seg_ptr, counts, counts_f32
+        st._schedule(csr, max_degree)
+        return st
+
+    @staticmethod
+    def _csr_from_sorted(lib, rows, cols, vals, n, stream, compact_flags, asym_flag, maxdeg_flag) -> _Csr:
+        """CSR arrays, compact columns, and (into the given device flag slots) the compact structure's two
+        verdicts, the number of asymmetric entries and the largest row.  Nothing is read back here."""
         dev = rows.device
         nnz = rows.numel()
         crow = torch.empty(n + 1, dtype=torch.int32, device=dev)
@@ -192,18 +220,22 @@ class GraphStructure:
         csr = _Csr(crow, col, val)
         if nnz:
             csr.col16 = torch.empty(nnz, dtype=torch.int16, device=dev)
-            csr.unit_values = torch.zeros(2, dtype=torch.int32, device=dev)      # flags until _schedule reads them
             _lib.check(lib.rwk_csr_compact(crow.data_ptr(), col.data_ptr(), val.data_ptr(), n, csr.col16.data_ptr(),
-                                           csr.unit_values.data_ptr(), stream), "rwk_csr_compact")
+                                           compact_flags.data_ptr(), stream), "rwk_csr_compact")
+            if asym_flag is not None:
+                _lib.check(lib.rwk_csr_count_asymmetric(crow.data_ptr(), col.data_ptr(), val.data_ptr(), n,
+                                                        asym_flag.data_ptr(), stream), "rwk_csr_count_asymmetric")
+            torch.amax(crow[1:] - crow[:-1], dim=0, keepdim=True, out=maxdeg_flag[:1])
         return csr
+
+    @staticmethod
+    def _apply_flags(csr: _Csr, too_far: int, weighted: int):
+        if too_far:
+            csr.col16 = None
+        csr.unit_values = weighted == 0
 
     def _schedule(self, csr: _Csr, max_degree: int):
         csr.max_degree = int(max_degree)
-        if torch.is_tensor(csr.unit_values):
-            too_far, weighted = csr.unit_values.cpu().tolist()
-            if too_far:
-                csr.col16 = None
-            csr.unit_values = weighted == 0
         csr.row_lanes, csr.long_threshold = spmm_schedule(self.n, self.nnz, csr.max_degree)
         if csr.long_threshold:
             deg = csr.crow[1:] - csr.crow[:-1]
@@ -286,11 +318,19 @@ class IdentityCache:
     def put(self, key, st, owners):
         import weakref
         self.entries[key] = st
+        self.entries.move_to_end(key)
         for t in owners:
             if t is not None:
-                weakref.finalize(t, self.entries.pop, key, None)
+                weakref.finalize(t, self._drop, key, id(st))
         while len(self.entries) > self.capacity:
             self.entries.popitem(last=False)
+
+    def _drop(self, key, st_id):
+        # only the entry this owner registered: buffers that are reused (batch slots) meet the same key again, and a
+        # late finalizer of the previous batch's tensors must not remove the new batch's entry
+        st = self.entries.get(key)
+        if st is not None and id(st) == st_id:
+            del self.entries[key]
 
     def clear(self):
         self.entries.clear()
@@ -319,6 +359,12 @@ def get_structure(adj, graph_indicator) -> GraphStructure:
     st = GraphStructure.build(adj, graph_indicator)
     _CACHE.put(key, st, (adj, graph_indicator))
     return st
+
+
+def register_structure(adj, graph_indicator, st: GraphStructure):
+    """Enter a structure built elsewhere (``DeviceDataset.batch``) for this ``(adj, graph_indicator)`` pair; it
+    replaces any entry with the same key (reused batch buffers)."""
+    _CACHE.put(_key(adj, graph_indicator), st, (adj, graph_indicator))
 
 
 def clear_structure_cache():

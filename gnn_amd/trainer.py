@@ -18,7 +18,7 @@ from .dp import FlatGradBucket
 from .losses import cross_entropy
 from .optim import FlatAdam, StepTail
 
-__all__ = ["Trainer", "EpochTrainer"]
+__all__ = ["Trainer", "EpochTrainer", "StreamTrainer"]
 
 
 class Trainer:
@@ -335,3 +335,62 @@ class EpochTrainer(Trainer):
     def run_epoch(self):
         self.g_epoch.replay()
         return self.epoch_losses
+
+
+class StreamTrainer(Trainer):
+    """Training over batches that are never resident twice: a pass over a ``gnn_amd.data.DeviceDataset`` in batches
+    of graph ids, each assembled on the device right before its step (the reference assembles all batches of a fold
+    up front, ``rwgnn2/main.py:70-72``; a data set of a million graphs is streamed instead).
+
+    Batch t+1 (``DeviceDataset.batch``: one upload, one launch, the structure included) is issued on a side stream
+    before step t is launched, into one of ``depth`` preallocated slots, so its assembly runs under step t and
+    nothing is allocated per batch; the side stream waits for the step that last used the slot, the launch stream
+    waits for the assembly.  Steps are launched eagerly (every batch has its own shape, so there is no graph to
+    replay); the host never waits for the device inside a pass.  Same arithmetic, same order as stepping the same
+    batches one by one: the parameters after a pass are the same bits."""
+
+    def __init__(self, model, dataset, max_graphs: int, max_nodes: int, max_nnz: int, depth: int = 3, **kw):
+        if kw.get("world", 1) != 1 and kw.get("capture_collective"):
+            raise ValueError("a streamed step is launched eagerly: nothing to capture the collective in")
+        self.dataset = dataset
+        self.slots = dataset.make_slots(depth, max_graphs, max_nodes, max_nnz)
+        self.build_stream = torch.cuda.Stream(device=dataset.device)
+        self.slot_free = [None] * depth         # event: the step that last read slot k has been queued and run
+        first = dataset.batch(list(range(min(2, dataset.n_graphs))))
+        super().__init__(model, first, **kw)
+        self.pass_losses = []
+
+    def _prepare(self, ids, k):
+        """Issue the assembly of a batch into slot ``k`` on the side stream; returns (batch, ready event)."""
+        with torch.cuda.stream(self.build_stream):
+            if self.slot_free[k] is not None:
+                self.build_stream.wait_event(self.slot_free[k])
+            batch = self.dataset.batch(ids, slot=self.slots[k])
+            ready = torch.cuda.Event()
+            ready.record(self.build_stream)
+        return batch, ready
+
+    def run_pass(self, id_lists, keep_losses: bool = True):
+        """One training step per entry of ``id_lists`` (lists of graph ids of the data set), in order.  Returns the
+        per-batch loss tensors (read them after the pass)."""
+        main = torch.cuda.current_stream(self.dataset.device)
+        depth = len(self.slots)
+        losses = []
+        nxt = self._prepare(id_lists[0], 0) if len(id_lists) else None
+        for t in range(len(id_lists)):
+            batch, ready = nxt
+            if t + 1 < len(id_lists):
+                nxt = self._prepare(id_lists[t + 1], (t + 1) % depth)
+            main.wait_event(ready)
+            self.adj, self.feats, self.gi, self.y = batch
+            self.fwd_bwd()
+            if self.world > 1:
+                self._all_reduce()
+            self._opt_step()
+            done = torch.cuda.Event()
+            done.record(main)
+            self.slot_free[t % depth] = done
+            if keep_losses:
+                losses.append(self.loss.detach())
+        self.pass_losses = losses
+        return losses

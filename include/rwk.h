@@ -71,7 +71,9 @@ int rwk_csr_count_asymmetric(const int32_t *crow, const int32_t *col, const floa
 
 /* Inspect graph_indicator (model.py:32).  flags (int32[4], zeroed by caller):
  *   [0] = number of positions p>0 with gi[p] < gi[p-1]  (0 <=> already sorted)
- *   [1] = max id, [2] = number of negative ids. */
+ *   [1] = max id, [2] = number of negative ids,
+ *   [3] = number of positions with gi[p] > gi[p-1] + 1, plus one if gi[0] != 0: for sorted ids, 0 <=> the ids
+ *         cover 0..max without gaps (torch.unique's counts then have no empty graph). */
 int rwk_indicator_inspect(const int64_t *gi, int64_t n, int32_t *flags, rwk_stream_t stream);
 
 /* From graph ids in sorted-position order (int64, non-decreasing, values in [0,G)):
@@ -93,6 +95,22 @@ int rwk_segments_build(const int64_t *ids_sorted, int64_t n, int64_t n_graphs, i
 int rwk_batch_gather_coo(const int64_t *ds_row_ptr, const int32_t *ds_col, const float *ds_val,
                          const int64_t *src_node, const int64_t *col_delta, const int64_t *out_ptr,
                          int64_t n, int64_t *rows, int64_t *cols, float *vals, rwk_stream_t stream);
+
+/* A batch and its structure in ONE launch (generate_batches' loop body utils.py:60-83 together with what
+ * torch.unique, model.py:32, and torch.spmm's COO->CSR conversion, model.py:55, derive from the batch on every
+ * call).  The data set is the block-diagonal CSR of rwk_batch_gather_coo with features ds_feat (N_all, n_feat)
+ * and labels ds_y.  table is int64 (4, b+1) on the device, computed by the host from its per-graph sizes:
+ *   row 0: first batch node of batch graph j (entry b = n), row 1: first data-set node of that graph,
+ *   row 2: first stored entry of the graph in the batch (entry b = nnz), row 3: the graph's id in the data set.
+ * Outputs (each may be NULL; the three COO arrays only together): the batch's COO list as
+ * rwk_batch_gather_coo writes it, feat (n, n_feat), gi = graph_indicator (n), y (b); the int32 CSR
+ * (crow n+1, col, val), col16 as rwk_csr_compact writes it (ask for it only when every graph of the batch has
+ * at most 32512 nodes), and gid, seg_ptr (b+1), counts, counts_f32 as rwk_segments_build writes them. */
+int rwk_batch_build(const int64_t *ds_row_ptr, const int32_t *ds_col, const float *ds_val, const float *ds_feat,
+                    int64_t n_feat, const int64_t *ds_y, const int64_t *table, int64_t b, int64_t n, int64_t nnz,
+                    int64_t *coo_rows, int64_t *coo_cols, float *coo_vals, float *feat, int64_t *gi, int64_t *y,
+                    int32_t *crow, int32_t *col, float *val, int16_t *col16, int32_t *gid, int32_t *seg_ptr,
+                    int64_t *counts, float *counts_f32, rwk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * (1) CSR SpMM   y = A x (+ y)          replaces torch.spmm, model.py:55, and its backward

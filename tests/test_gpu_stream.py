@@ -1,0 +1,165 @@
+"""Batches that change every step: the one-launch batch assembly (``DeviceDataset.batch``) against the generic
+structure build, and a streamed training pass (``StreamTrainer``: assembly of batch t+1 on a side stream under step
+t, reused buffers, no host wait) against the same batches stepped one by one.  Integer work and replays of the same
+arithmetic: everything here is bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _structure_arrays(st):
+    c = st.csr
+    out = {"crow": c.crow, "col": c.col, "val": c.val, "gid": st.gid, "seg_ptr": st.seg_ptr, "counts": st.counts,
+           "counts_f32": st.counts_f32}
+    if c.col16 is not None:
+        out["col16"] = c.col16
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def _assert_same_structure(a, b):
+    assert (a.n, a.nnz, a.n_graphs, a.symmetric) == (b.n, b.nnz, b.n_graphs, b.symmetric)
+    assert (a.csr.max_degree, a.csr.row_lanes, a.csr.long_threshold, bool(a.csr.unit_values)) == \
+        (b.csr.max_degree, b.csr.row_lanes, b.csr.long_threshold, bool(b.csr.unit_values))
+    assert (a.csr.col16 is None) == (b.csr.col16 is None)
+    assert a.perm is None and b.perm is None and a.csr_t is a.csr and b.csr_t is b.csr
+    xa, xb = _structure_arrays(a), _structure_arrays(b)
+    assert xa.keys() == xb.keys()
+    for k in xa:
+        assert xa[k].dtype == xb[k].dtype and np.array_equal(xa[k], xb[k]), k
+
+
+@pytest.mark.parametrize("n_feat", [None, 3, 16])
+def test_batch_build_equals_generic_structure_build(n_feat):
+    """The arrays ``rwk_batch_build`` writes next to the batch are those ``GraphStructure.build`` derives from the
+    batch's tensors; through fresh tensors and through a reused slot."""
+    dev = _dev()
+    from gnn_amd.data import DeviceDataset
+    from gnn_amd.structure import GraphStructure, get_structure
+    from gnn_amd.synth import random_batch
+    whole = random_batch(300, 1, 40, 2.2, seed=5, n_feat=n_feat)
+    ds = DeviceDataset.from_batch(whole, dev)
+    assert ds.symmetric and ds.unit_values
+    rng = np.random.default_rng(0)
+    slots = ds.make_slots(1, 64, 64 * 40, int(ds.edge_ptr_h[-1]))
+    for trial in range(4):
+        ids = rng.permutation(300)[:rng.integers(1, 65)]
+        for slot in (None, slots[0]):
+            adj, feats, gi, y = ds.batch(ids, slot=slot)
+            ref = whole_slices(whole, ids)
+            assert np.array_equal(adj._indices().cpu().numpy(), ref[0])
+            assert np.array_equal(adj._values().cpu().numpy(), ref[1])
+            assert np.array_equal(feats.cpu().numpy(), ref[2])
+            assert np.array_equal(gi.cpu().numpy(), ref[3])
+            assert np.array_equal(y.cpu().numpy(), ref[4])
+            assert ds.batch_shape(ids) == (gi.numel(), adj._values().numel())
+            st = get_structure(adj, gi)                      # registered by batch(): no build, no device read
+            _assert_same_structure(st, GraphStructure.build(adj, gi))
+
+
+def whole_slices(whole, ids):
+    """The batch made of graphs ``ids`` of a synthetic block-diagonal batch, by numpy."""
+    starts = np.concatenate([[0], np.cumsum(whole.sizes)])
+    r, c = whole.indices
+    rows, cols, vals, feats, gi = [], [], [], [], []
+    off = 0
+    for j, g in enumerate(ids):
+        a, b = int(starts[g]), int(starts[g + 1])
+        sel = (r >= a) & (r < b)
+        rows.append(r[sel] - a + off)
+        cols.append(c[sel] - a + off)
+        vals.append(whole.values[sel])
+        feats.append(whole.features[a:b])
+        gi.append(np.full(b - a, j, dtype=np.int64))
+        off += b - a
+    return (np.vstack([np.concatenate(rows), np.concatenate(cols)]), np.concatenate(vals), np.vstack(feats),
+            np.concatenate(gi), whole.y[np.asarray(ids)])
+
+
+def test_generic_build_reads_the_device_once(monkeypatch):
+    """A batch of foreign tensors (row-major sorted COO, sorted ids: what generate_batches produces) costs one
+    device-to-host read."""
+    dev = _dev()
+    from gnn_amd.structure import GraphStructure
+    from gnn_amd.synth import random_batch
+    adj, _, gi, _ = random_batch(20, 5, 30, 3.0, seed=2).to_torch(dev)
+    reads = []
+    real_cpu, real_item = torch.Tensor.cpu, torch.Tensor.item
+    monkeypatch.setattr(torch.Tensor, "cpu", lambda t, *a, **k: (reads.append("cpu"), real_cpu(t, *a, **k))[1])
+    monkeypatch.setattr(torch.Tensor, "item", lambda t: (reads.append("item"), real_item(t))[1])
+    st = GraphStructure.build(adj, gi)
+    assert reads == ["cpu"] and st.n_graphs == 20 and st.symmetric
+
+
+def test_asymmetric_data_set_falls_back_to_the_generic_build():
+    dev = _dev()
+    from gnn_amd.data import DeviceDataset
+    from gnn_amd.structure import get_structure
+    # two directed 3-cycles
+    node_ptr = [0, 3, 6]
+    row_ptr = [0, 1, 2, 3, 4, 5, 6]
+    col = [1, 2, 0, 4, 5, 3]
+    ds = DeviceDataset.from_arrays(node_ptr, row_ptr, col, np.ones(6, np.float32), np.ones((6, 1), np.float32), [0, 1],
+                                   dev)
+    assert not ds.symmetric
+    adj, _, gi, _ = ds.batch([1, 0])
+    st = get_structure(adj, gi)
+    assert not st.symmetric and st.csr_t is not st.csr
+    assert st.csr_t.col.cpu().tolist() == [2, 0, 1, 5, 3, 4]
+
+
+@pytest.mark.parametrize("shape", ["register", "matrix_core"])
+def test_streamed_pass_equals_batches_stepped_one_by_one(shape):
+    dev = _dev()
+    from gnn_amd import RW_NN
+    from gnn_amd.data import DeviceDataset
+    from gnn_amd.structure import clear_structure_cache
+    from gnn_amd.synth import random_batch
+    from gnn_amd.trainer import StreamTrainer, Trainer
+    if shape == "register":
+        whole = random_batch(640, 20, 60, 3.0, seed=11)
+        hp = dict(input_dim=1, max_step=2, hidden_graphs=16, size_hidden_graphs=5, hidden_dim=4)
+    else:
+        whole = random_batch(640, 10, 40, 2.2, seed=12, n_feat=16)
+        hp = dict(input_dim=16, max_step=2, hidden_graphs=64, size_hidden_graphs=10, hidden_dim=64)
+    ds = DeviceDataset.from_batch(whole, dev)
+    rng = np.random.default_rng(3)
+    order = rng.permutation(640)
+    id_lists = [order[i:i + 64] for i in range(0, 640, 64)]
+    id_lists[3] = id_lists[3][:17]                       # a ragged batch in the middle
+
+    def model():
+        torch.manual_seed(0)
+        m = RW_NN(hp["input_dim"], hp["max_step"], hp["hidden_graphs"], hp["size_hidden_graphs"], hp["hidden_dim"],
+                  32, False, 2, 0.2, dev).to(dev).train()
+        m.seed_dropout(77)
+        return m
+
+    shapes = [ds.batch_shape(ids) for ids in id_lists]
+    st = StreamTrainer(model(), ds, 64, max(s[0] for s in shapes), max(s[1] for s in shapes), depth=3)
+    losses_s = st.run_pass(id_lists)
+    losses_s += st.run_pass(id_lists[::-1])              # a second pass reuses every slot again
+    torch.cuda.synchronize()
+
+    one = Trainer(model(), ds.batch(id_lists[0]))
+    losses_o = []
+    for ids in id_lists + id_lists[::-1]:
+        b = ds.batch(ids)
+        clear_structure_cache()                           # the step derives the structure from the tensors itself
+        one.adj, one.feats, one.gi, one.y = b
+        one.step_eager()
+        torch.cuda.synchronize()
+        losses_o.append(one.loss.detach())
+    assert [float(v) for v in losses_s] == [float(v) for v in losses_o]
+    assert all(np.isfinite(float(v)) for v in losses_s)
+    for a, b in ((st.opt.flat_param, one.opt.flat_param), (st.opt.exp_avg, one.opt.exp_avg),
+                 (st.opt.exp_avg_sq, one.opt.exp_avg_sq), (st.model.bn.running_mean, one.model.bn.running_mean),
+                 (st.model.bn.running_var, one.model.bn.running_var), (st.model._rng_state, one.model._rng_state)):
+        assert torch.equal(a, b)
