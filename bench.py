@@ -74,6 +74,10 @@ def parse_args():
     ap.add_argument("--dp-shape", type=int, default=0,
                     help="one GPU only: time the step in the shape a rank of an N-rank run executes (two graphs and "
                          "the collective's slot between them, no process group) to see what the shape itself costs")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="--gpus N: weak = every rank its own batch of the configuration (default); strong = ONE batch "
+                         "of the configuration cut into N contiguous graph ranges balanced by node count "
+                         "(gnn_amd.dp.shard_ranges), total work fixed")
     ap.add_argument("--stream", action="store_true",
                     help="never-repeating batches: a pool of --pool-batches distinct batches of the configuration as "
                          "one device-resident data set, each batch assembled (DeviceDataset.batch, structure included) "
@@ -343,7 +347,8 @@ def distinct_batches_epoch(config, hp, dev, k, epochs=8, seed0=100):
 class StreamBench:
     """A pool of distinct batches of a configuration as one device-resident data set, streamed batch by batch."""
 
-    def __init__(self, config, hp, dev, pool_batches, seed, optimizer="flat", world=1, sync_before_all_reduce=False):
+    def __init__(self, config, hp, dev, pool_batches, seed, optimizer="flat", world=1, sync_before_all_reduce=False,
+                 side_stream=True):
         from gnn_amd.data import DeviceDataset
         from gnn_amd.synth import config_batch
         from gnn_amd.trainer import StreamTrainer
@@ -354,7 +359,8 @@ class StreamBench:
         shapes = [self.ds.batch_shape(ids) for ids in self.id_lists]
         self.nodes = sum(s[0] for s in shapes)
         self.tr = StreamTrainer(_new_model(hp, dev, seed), self.ds, self.per_batch, max(s[0] for s in shapes),
-                                max(s[1] for s in shapes), depth=3, world=world, optimizer=optimizer,
+                                max(s[1] for s in shapes), depth=3, side_stream=side_stream, world=world,
+                                optimizer=optimizer,
                                 sync_before_all_reduce=sync_before_all_reduce)
         self.cursor = 0
 
@@ -480,7 +486,13 @@ def main():
     hp = dict(cfg["hp"])
     if args.dropout is not None:
         hp["dropout"] = args.dropout
-    batch = config_batch(args.config, seed=1 + rank, scale=args.scale)     # each rank its own graphs
+    if args.scaling == "strong" and world > 1:
+        from gnn_amd.dp import shard_ranges
+        whole = config_batch(args.config, seed=1, scale=args.scale)         # the same batch on every rank ...
+        lo, hi = shard_ranges(whole.sizes, world)[rank]                     # ... cut by node count
+        batch = whole.slice_graphs(lo, hi)
+    else:
+        batch = config_batch(args.config, seed=1 + rank, scale=args.scale)  # each rank its own graphs
     batch_t = batch.to_torch(dev)
 
     if args.kernels_only:
@@ -610,7 +622,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -620,7 +632,8 @@ def main():
                             f"L{hp['max_step']} dropout {hp['dropout']}",
                 "step": "zero_grad + forward + cross_entropy + backward + grad all-reduce + Adam (%s)" % args.optimizer,
                 "launch": launch,
-                "parallelism": f"dp{world} (graphs sharded, one flat-bucket all-reduce)",
+                "parallelism": f"dp{world} (graphs sharded, one flat-bucket all-reduce)" + (
+                    "; one batch cut into node-balanced graph ranges" if (args.scaling == "strong" and world > 1) else ""),
             },
             "final_loss": round(loss, 5),
             # the same K steps between two events on the launch stream (rank 0): what the host clock adds

@@ -148,11 +148,11 @@ struct BatchBuildArgs {
     int64_t *counts;
     float *counts_f32;
     int64_t node_blocks;
+    int feat_vec4;
 };
 
-// last g in [0, b) with start[g] <= v
-__device__ inline int64_t graph_of_node(const int64_t *__restrict__ start, int64_t b, int64_t v) {
-    int64_t lo = 0, hi = b;
+// last g in [lo, hi) with start[g] <= v
+__device__ inline int64_t graph_of_node(const int64_t *__restrict__ start, int64_t lo, int64_t hi, int64_t v) {
     while (hi - lo > 1) {
         const int64_t mid = (lo + hi) >> 1;
         if (start[mid] <= v) lo = mid; else hi = mid;
@@ -160,21 +160,52 @@ __device__ inline int64_t graph_of_node(const int64_t *__restrict__ start, int64
     return lo;
 }
 
+// The graphs of the nodes v0 .. v1 (of one workgroup) form a range g0 .. g1: two lanes find its ends in the table,
+// the workgroup copies that slice of the node offsets to LDS, and every thread then searches its own node there
+// (a thread-private search of the whole table is twelve dependent trips to the L2 at 4096 graphs).
+constexpr int kSliceMax = 512;
+
+__device__ inline int64_t graph_of_node_block(const int64_t *__restrict__ new_start, int64_t b, int64_t v0, int64_t v1,
+                                              int64_t v, bool active, int64_t *slice, int64_t *ends) {
+    if (threadIdx.x < 2) ends[threadIdx.x] = graph_of_node(new_start, 0, b, threadIdx.x == 0 ? v0 : v1);
+    __syncthreads();
+    const int64_t g0 = ends[0], g1 = ends[1];
+    const int64_t len = g1 - g0 + 1;
+    if (len <= kSliceMax) {
+        for (int64_t i = threadIdx.x; i < len; i += kBlock) slice[i] = new_start[g0 + i];
+        __syncthreads();
+        return active ? g0 + graph_of_node(slice, 0, len, v) : 0;
+    }
+    return active ? graph_of_node(new_start, g0, g1 + 1, v) : 0;
+}
+
 __global__ void __launch_bounds__(kBlock) batch_build_kernel(const BatchBuildArgs a) {
+    __shared__ int64_t slice[kSliceMax];
+    __shared__ int64_t ends[2];
     const int64_t *__restrict__ new_start = a.table;
     const int64_t *__restrict__ old_start = a.table + (a.b + 1);
     const int64_t *__restrict__ new_entry = a.table + 2 * (a.b + 1);
     const int64_t *__restrict__ graph_id = a.table + 3 * (a.b + 1);
     if ((int64_t)blockIdx.x >= a.node_blocks) {
-        // wide feature rows: one element per thread, coalesced along the row
-        const int64_t e = ((int64_t)blockIdx.x - a.node_blocks) * kBlock + threadIdx.x;
-        if (e >= a.n * a.n_feat) return;
-        const int64_t v = e / a.n_feat, k = e - v * a.n_feat;
-        const int64_t g = graph_of_node(new_start, a.b, v);
-        a.feat[e] = a.ds_feat[(old_start[g] + (v - new_start[g])) * a.n_feat + k];
+        // wide feature rows: one element (16 bytes when rows are whole float4s) per thread, coalesced along the row
+        const int64_t q = a.feat_vec4 ? (a.n_feat >> 2) : a.n_feat;
+        const int64_t e0 = ((int64_t)blockIdx.x - a.node_blocks) * kBlock;
+        const int64_t e = e0 + threadIdx.x;
+        const int64_t total = a.n * q;
+        const int64_t e_last = (e0 + kBlock - 1 < total ? e0 + kBlock - 1 : total - 1);
+        const bool active = e < total;
+        const int64_t v = active ? e / q : 0, k = e - v * q;
+        const int64_t g = graph_of_node_block(new_start, a.b, e0 / q, e_last / q, v, active, slice, ends);
+        if (!active) return;
+        const int64_t src = (old_start[g] + (v - new_start[g])) * q + k;
+        if (a.feat_vec4)
+            reinterpret_cast<float4 *__restrict__>(a.feat)[e] = reinterpret_cast<const float4 *__restrict__>(a.ds_feat)[src];
+        else
+            a.feat[e] = a.ds_feat[src];
         return;
     }
-    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t t0 = (int64_t)blockIdx.x * kBlock;
+    const int64_t t = t0 + threadIdx.x;
     if (t < a.b) {
         const int64_t s0 = new_start[t], s1 = new_start[t + 1];
         if (a.seg_ptr) {
@@ -185,13 +216,18 @@ __global__ void __launch_bounds__(kBlock) batch_build_kernel(const BatchBuildArg
         if (a.counts_f32) a.counts_f32[t] = (float)(s1 - s0);
         if (a.y) a.y[t] = a.ds_y[graph_id[t]];
     }
-    if (t >= a.n) return;
-    const int64_t g = graph_of_node(new_start, a.b, t);
-    const int64_t first_old = old_start[g];
-    const int64_t src = first_old + (t - new_start[g]);
-    const int64_t beg = a.ds_row_ptr[src], end = a.ds_row_ptr[src + 1];
-    int64_t o = new_entry[g] + (beg - a.ds_row_ptr[first_old]);
-    const int64_t delta = new_start[g] - first_old;
+    const bool active = t < a.n;
+    const int64_t t_last = t0 + kBlock - 1 < a.n ? t0 + kBlock - 1 : a.n - 1;
+    const int64_t g = graph_of_node_block(new_start, a.b, t0, t_last, t, active, slice, ends);
+    if (!active) return;
+    const int64_t first_new = new_start[g], first_old = old_start[g];
+    const int64_t src = first_old + (t - first_new);
+    const int64_t *__restrict__ row_ptr = a.ds_row_ptr;
+    const int32_t *__restrict__ ds_col = a.ds_col;
+    const float *__restrict__ ds_val = a.ds_val;
+    const int64_t beg = row_ptr[src], end = row_ptr[src + 1];
+    int64_t o = new_entry[g] + (beg - row_ptr[first_old]);
+    const int64_t delta = first_new - first_old;
     if (a.crow) {
         a.crow[t] = (int32_t)o;
         if (t == a.n - 1) a.crow[a.n] = (int32_t)(o + (end - beg));
@@ -201,17 +237,23 @@ __global__ void __launch_bounds__(kBlock) batch_build_kernel(const BatchBuildArg
     if (a.feat && a.n_feat <= 4)
         for (int64_t k = 0; k < a.n_feat; ++k) a.feat[t * a.n_feat + k] = a.ds_feat[src * a.n_feat + k];
     const int64_t base = t & ~(int64_t)255;
+    int64_t *__restrict__ coo_rows = a.coo_rows;
+    int64_t *__restrict__ coo_cols = a.coo_cols;
+    float *__restrict__ coo_vals = a.coo_vals;
+    int32_t *__restrict__ col = a.col;
+    float *__restrict__ val = a.val;
+    int16_t *__restrict__ col16 = a.col16;
     for (int64_t e = beg; e < end; ++e, ++o) {
-        const int64_t c = (int64_t)a.ds_col[e] + delta;
-        const float w = a.ds_val[e];
-        if (a.coo_rows) {
-            a.coo_rows[o] = t;
-            a.coo_cols[o] = c;
-            a.coo_vals[o] = w;
+        const int64_t c = (int64_t)ds_col[e] + delta;
+        const float w = ds_val[e];
+        if (coo_rows) {
+            coo_rows[o] = t;
+            coo_cols[o] = c;
+            coo_vals[o] = w;
         }
-        if (a.col) a.col[o] = (int32_t)c;
-        if (a.val) a.val[o] = w;
-        if (a.col16) a.col16[o] = (int16_t)(c - base);
+        if (col) col[o] = (int32_t)c;
+        if (val) val[o] = w;
+        if (col16) col16[o] = (int16_t)(c - base);
     }
 }
 
@@ -236,9 +278,11 @@ int rwk_batch_build(const int64_t *ds_row_ptr, const int32_t *ds_col, const floa
     if ((coo_rows == nullptr) != (coo_cols == nullptr) || (coo_rows == nullptr) != (coo_vals == nullptr))
         return RWK_E_NULL;
     BatchBuildArgs a{ds_row_ptr, ds_col, ds_val, ds_feat, ds_y, table, b, n, nnz, n_feat, coo_rows, coo_cols,
-                     coo_vals, feat, gi, y, crow, col, val, col16, gid, seg_ptr, counts, counts_f32, 0};
+                     coo_vals, feat, gi, y, crow, col, val, col16, gid, seg_ptr, counts, counts_f32, 0, 0};
     a.node_blocks = rwk_ceil_div(n, kBlock);
-    const int64_t feat_blocks = (feat != nullptr && n_feat > 4) ? rwk_ceil_div(n * n_feat, kBlock) : 0;
+    a.feat_vec4 = (n_feat % 4 == 0) && ((((uintptr_t)feat | (uintptr_t)ds_feat) & 15u) == 0);
+    const int64_t feat_blocks =
+        (feat != nullptr && n_feat > 4) ? rwk_ceil_div(a.feat_vec4 ? n * (n_feat / 4) : n * n_feat, kBlock) : 0;
     if (a.node_blocks + feat_blocks >= 0x7FFFFFFFll) return RWK_E_SIZE;
     hipLaunchKernelGGL(batch_build_kernel, dim3((unsigned)(a.node_blocks + feat_blocks)), dim3(kBlock), 0,
                        (hipStream_t)stream, a);

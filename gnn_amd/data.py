@@ -23,7 +23,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["load_data", "generate_batches", "DeviceDataset"]
+__all__ = ["load_data", "generate_batches", "DeviceDataset", "BatchPlan"]
 
 
 def load_data(ds_name: str, use_node_labels: bool, root: str = "datasets"):
@@ -180,36 +180,51 @@ class DeviceDataset:
             slots.append(s)
         return slots
 
+    def plan(self, id_lists) -> "BatchPlan":
+        """Host-side shapes and the device-side offset tables of a sequence of batches (lists of graph ids), uploaded
+        in one copy: :meth:`batch_planned` then assembles batch ``i`` with one launch and no transfer at all."""
+        metas, tables = [], []
+        off = 0
+        for graph_ids in id_lists:
+            ids = np.asarray(graph_ids, dtype=np.int64).reshape(-1)
+            b = int(ids.size)
+            if b == 0:
+                raise ValueError("empty batch")
+            if ids.min() < 0 or ids.max() >= self.n_graphs:
+                raise IndexError("graph id outside the data set")
+            table = np.zeros((4, b + 1), dtype=np.int64)
+            np.cumsum(self.node_ptr_h[ids + 1] - self.node_ptr_h[ids], out=table[0, 1:])
+            table[1, :b] = self.node_ptr_h[ids]
+            np.cumsum(self.edge_ptr_h[ids + 1] - self.edge_ptr_h[ids], out=table[2, 1:])
+            table[3, :b] = ids
+            n, nnz = int(table[0, b]), int(table[2, b])
+            if n == 0:
+                raise ValueError("empty batch")
+            # |column - first row of the row's 256-row block| must fit int16 for the compact columns
+            fits16 = int(np.diff(table[0]).max()) + 255 <= 32767
+            metas.append((b, n, nnz, int(self.graph_max_degree_h[ids].max()), fits16, off))
+            tables.append(table.reshape(-1))
+            off += table.size
+        flat = np.concatenate(tables) if len(tables) > 1 else tables[0]
+        with torch.cuda.device(self.device):
+            dev_tables = torch.from_numpy(flat).pin_memory().to(self.device, non_blocking=True)
+        return BatchPlan(dev_tables, metas)
+
     def batch(self, graph_ids, slot: "_Slot" = None):
         """(adj, features, graph_indicator, y) of the batch made of these graphs, in this order (the loop body of
         ``utils.py:60-83``), with the batch's structure already in the structure cache: ``get_structure(adj,
         graph_indicator)`` - what ``RW_NN.forward`` calls first - finds it without building or reading anything.
         No device-to-host read, one upload (4 x (graphs + 1) int64), one launch on the current stream."""
+        return self.batch_planned(self.plan([graph_ids]), 0, slot)
+
+    def batch_planned(self, plan: "BatchPlan", i: int, slot: "_Slot" = None):
+        """Batch ``i`` of a :meth:`plan`: one launch (``rwk_batch_build``) on the current stream."""
         from .structure import GraphStructure, register_structure
         lib = _lib.load()
         dev = self.device
-        ids = np.asarray(graph_ids, dtype=np.int64).reshape(-1)
-        b = int(ids.size)
-        if b == 0:
-            raise ValueError("empty batch")
-        if ids.min() < 0 or ids.max() >= self.n_graphs:
-            raise IndexError("graph id outside the data set")
-        table = np.empty((4, b + 1), dtype=np.int64)
-        table[0, 0] = table[2, 0] = 0
-        np.cumsum(self.node_ptr_h[ids + 1] - self.node_ptr_h[ids], out=table[0, 1:])
-        table[1, :b] = self.node_ptr_h[ids]
-        np.cumsum(self.edge_ptr_h[ids + 1] - self.edge_ptr_h[ids], out=table[2, 1:])
-        table[3, :b] = ids
-        table[1, b] = table[3, b] = 0
-        n, nnz = int(table[0, b]), int(table[2, b])
-        if n == 0:
-            raise ValueError("empty batch")
-        max_graph = int(np.diff(table[0]).max())
-        max_degree = int(self.graph_max_degree_h[ids].max())
-        fits16 = max_graph + 255 <= 32767          # |column - first row of the row's 256-row block| within int16
+        b, n, nnz, max_degree, fits16, off = plan.metas[i]
         f = self.n_feat
-        with torch.cuda.device(dev):
-            table_d = torch.from_numpy(table).pin_memory().to(dev, non_blocking=True)
+        with _lib.device_guard(dev):
             if slot is None:
                 idx = torch.empty((2, nnz), dtype=torch.int64, device=dev)
                 vals = torch.empty(nnz, dtype=torch.float32, device=dev)
@@ -237,10 +252,11 @@ class DeviceDataset:
                 gid, seg_ptr = slot.gid[:n], slot.seg_ptr[:b + 1]
                 counts, counts_f32 = slot.counts[:b], slot.counts_f32[:b]
             nz = nnz > 0
+            rows_p = idx.data_ptr() if nz else None
             _lib.check(lib.rwk_batch_build(
                 self.row_ptr.data_ptr(), _lib.ptr(self.col), _lib.ptr(self.val), self.features.data_ptr(), f,
-                self.y.data_ptr(), table_d.data_ptr(), b, n, nnz,
-                idx[0].data_ptr() if nz else None, idx[1].data_ptr() if nz else None, vals.data_ptr() if nz else None,
+                self.y.data_ptr(), plan.tables.data_ptr() + 8 * off, b, n, nnz,
+                rows_p, rows_p + 8 * nnz if nz else None, vals.data_ptr() if nz else None,
                 feats.data_ptr() if f else None, gi.data_ptr(), yy.data_ptr(), crow.data_ptr(),
                 col.data_ptr() if nz else None, val.data_ptr() if nz else None, _lib.ptr(col16), gid.data_ptr(),
                 seg_ptr.data_ptr(), counts.data_ptr(), counts_f32.data_ptr(), _lib.current_stream(dev)),
@@ -249,9 +265,21 @@ class DeviceDataset:
             if self.symmetric:
                 st = GraphStructure.from_parts(dev, n, nnz, b, crow, col, val, col16, self.unit_values, max_degree,
                                                gid, seg_ptr, counts, counts_f32)
+                st.plan_tables = plan.tables       # the launch reads them asynchronously
                 register_structure(adj, gi, st)
             # an asymmetric data set needs the transposed CSR as well: get_structure builds it on first use
             return adj, feats, gi, yy
+
+
+class BatchPlan:
+    """Offset tables of a sequence of batches on the device and their host-side shapes (``DeviceDataset.plan``)."""
+    __slots__ = ("tables", "metas")
+
+    def __init__(self, tables, metas):
+        self.tables, self.metas = tables, metas
+
+    def __len__(self):
+        return len(self.metas)
 
 
 def generate_batches(adj, features, y, batch_size, device, shuffle=False):

@@ -85,6 +85,7 @@ class GraphStructure:
         self.counts = None       # int64 (G)  == torch.unique(..., return_counts=True)[1]
         self.counts_f32 = None   # float32 (G)
         self.plans = {}          # launch constants per hyper-parameter set (gnn_amd.function._plan)
+        self.plan_tables = None  # device buffer the assembling launch reads (DeviceDataset.batch_planned)
 
     # ------------------------------------------------------------------------------------
     @staticmethod

@@ -349,23 +349,27 @@ class StreamTrainer(Trainer):
     replay); the host never waits for the device inside a pass.  Same arithmetic, same order as stepping the same
     batches one by one: the parameters after a pass are the same bits."""
 
-    def __init__(self, model, dataset, max_graphs: int, max_nodes: int, max_nnz: int, depth: int = 3, **kw):
+    def __init__(self, model, dataset, max_graphs: int, max_nodes: int, max_nnz: int, depth: int = 3,
+                 side_stream: bool = True, **kw):
         if kw.get("world", 1) != 1 and kw.get("capture_collective"):
             raise ValueError("a streamed step is launched eagerly: nothing to capture the collective in")
         self.dataset = dataset
         self.slots = dataset.make_slots(depth, max_graphs, max_nodes, max_nnz)
-        self.build_stream = torch.cuda.Stream(device=dataset.device)
+        # side_stream=False: the assembly is launched on the step's own stream, in front of the step
+        self.build_stream = torch.cuda.Stream(device=dataset.device) if side_stream else None
         self.slot_free = [None] * depth         # event: the step that last read slot k has been queued and run
         first = dataset.batch(list(range(min(2, dataset.n_graphs))))
         super().__init__(model, first, **kw)
         self.pass_losses = []
 
-    def _prepare(self, ids, k):
-        """Issue the assembly of a batch into slot ``k`` on the side stream; returns (batch, ready event)."""
+    def _prepare(self, plan, i, k):
+        """Issue the assembly of batch ``i`` of the plan into slot ``k``; returns (batch, ready event or None)."""
+        if self.build_stream is None:
+            return self.dataset.batch_planned(plan, i, slot=self.slots[k]), None
         with torch.cuda.stream(self.build_stream):
             if self.slot_free[k] is not None:
                 self.build_stream.wait_event(self.slot_free[k])
-            batch = self.dataset.batch(ids, slot=self.slots[k])
+            batch = self.dataset.batch_planned(plan, i, slot=self.slots[k])
             ready = torch.cuda.Event()
             ready.record(self.build_stream)
         return batch, ready
@@ -376,20 +380,31 @@ class StreamTrainer(Trainer):
         main = torch.cuda.current_stream(self.dataset.device)
         depth = len(self.slots)
         losses = []
-        nxt = self._prepare(id_lists[0], 0) if len(id_lists) else None
+        if not len(id_lists):
+            return losses
+        plan = self.dataset.plan(id_lists)       # shapes on the host, offset tables in one upload for the whole pass
+        if self.build_stream is not None:
+            self.build_stream.wait_stream(main)
+        side = self.build_stream is not None
+        nxt = self._prepare(plan, 0, 0)
         for t in range(len(id_lists)):
             batch, ready = nxt
-            if t + 1 < len(id_lists):
-                nxt = self._prepare(id_lists[t + 1], (t + 1) % depth)
-            main.wait_event(ready)
+            if side and t + 1 < len(id_lists):
+                nxt = self._prepare(plan, t + 1, (t + 1) % depth)
+            if ready is not None:
+                main.wait_event(ready)
             self.adj, self.feats, self.gi, self.y = batch
             self.fwd_bwd()
             if self.world > 1:
                 self._all_reduce()
             self._opt_step()
-            done = torch.cuda.Event()
-            done.record(main)
-            self.slot_free[t % depth] = done
+            if side:
+                done = torch.cuda.Event()
+                done.record(main)
+                self.slot_free[t % depth] = done
+            elif t + 1 < len(id_lists):
+                # same stream: the next assembly is ordered behind this step by the stream itself
+                nxt = self._prepare(plan, t + 1, (t + 1) % depth)
             if keep_losses:
                 losses.append(self.loss.detach())
         self.pass_losses = losses
