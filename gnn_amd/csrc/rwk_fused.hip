@@ -815,6 +815,7 @@ const char *rwk_error_string(int code) {
         case RWK_E_STATIC_SIZE:
             return "the input exceeds the library's fixed device scratch (rwk_reduce_rows_static: more than "
                    "RWK_REDUCE_ROWS_STATIC_MAX_V columns); use the entry point that takes a workspace";
+        case RWK_E_DEVICE: return "the stream belongs to another device than the current one";
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);
     return "unknown error";

@@ -15,7 +15,11 @@
 // Rows of a tile are 16 hidden graphs at a fixed hidden node s, so the sum over s is a sum of accumulator
 // tiles in registers.  A workgroup owns one block of 16 hidden graphs (blockIdx.y) and keeps their Z rows of
 // all steps in LDS.  Columns are 16 independent streams of consecutive sorted positions, as in the
-// vector-ALU kernels: partial sums go to slot (stream + graph) of k_partials, no atomics anywhere.
+// vector-ALU kernels: partial sums go to slot (stream + graph) of k_partials, no atomics in the forward.  The
+// backward has ONE kind of float atomic: with more than one block of 16 hidden graphs, the first block stores its
+// share of dX and the later blocks add theirs at the L2 (global_atomic_add_f32 without return value).  Every dX
+// element has one owner lane that issues its store and its adds in block order, so the sum is formed in a fixed
+// order and the result is bitwise reproducible (the same bits as load + add + store).
 #include "rwk_fused_mfma.h"
 
 namespace rwk_mfma {

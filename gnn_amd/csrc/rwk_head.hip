@@ -2,7 +2,8 @@
 //   BatchNorm1d(C) -> Linear(C, P) -> ReLU -> Dropout(p) -> Linear(P, NC) -> log_softmax
 // (rwgnn2/model.py:68-72 and their autograd backward).  G rows (graphs) of C = max_step * hidden_graphs
 // kernel features; everything is tiny next to the random-walk layer, so the kernels are plain vector-ALU code
-// whose only aim is to be few launches, deterministic (fixed summation orders, no atomics) and exact fp32.
+// whose only aim is to be few launches, deterministic (fixed summation orders, no atomics in this file) and exact
+// fp32.
 //
 //   forward, training:  head_stats_kernel   per-block (count, mean, M2) of each column, merged by the pairwise-variance identity
 //                       head_apply_kernel   normalise, both linear layers, dropout, log-softmax; running stats

@@ -86,8 +86,10 @@ struct NoGradTail {
 };
 
 // workgroup `h` of kHiddenBlock threads; lds: 2*s*s + (1 + n_slices) * max_step*s*d floats
+// adj_hidden carries no __restrict__: with an optimiser tail attached the same thread writes the updated parameter
+// back to that memory (the tail's parameter buffer is the parameter itself).
 template <typename TAIL = NoGradTail>
-__device__ inline void hidden_backward_body(int h, float *lds, const float *__restrict__ adj_hidden,
+__device__ inline void hidden_backward_body(int h, float *lds, const float *adj_hidden,
                                             const float *__restrict__ ah_in, const float *__restrict__ z,
                                             const float *__restrict__ dz_partials, int n_partials, int n_hidden,
                                             int s, int d, int max_step, float *__restrict__ d_adj_hidden,

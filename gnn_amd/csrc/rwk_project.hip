@@ -225,10 +225,19 @@ constexpr int kMaxDevices = 64;
 std::mutex scratch_mutex;
 float *scratch_ptr[kMaxDevices] = {};        // device address of `scratch` on each GPU, nullptr = not looked up yet
 
-int scratch_for_current_device(float **out) {
+// The array's copy on the device the launches will run on: the device that owns `stream` (the current device for
+// the null stream).  That device must be the current one - the address is looked up with it current, and so are the
+// launches issued - otherwise RWK_E_DEVICE: no kernel ever gets another GPU's address.
+int scratch_for_stream_device(hipStream_t stream, float **out) {
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
+    if (stream != nullptr) {
+        hipDevice_t owner;
+        e = hipStreamGetDevice(stream, &owner);
+        if (e != hipSuccess) return (int)e;
+        if ((int)owner != dev) return RWK_E_DEVICE;
+    }
     if (dev < 0 || dev >= kMaxDevices) return RWK_E_UNSUPPORTED;
     std::lock_guard<std::mutex> lock(scratch_mutex);
     if (scratch_ptr[dev] == nullptr) {
@@ -252,7 +261,7 @@ extern "C" int rwk_reduce_rows_static(const float *in, int64_t p, int64_t v, flo
         // every element of the 32 x v level-1 block is written by the first launch (row blocks without rows write
         // zeros), so nothing of an earlier call's contents is read and nothing needs clearing
         if (v > kStaticMaxV) return RWK_E_STATIC_SIZE;
-        const int rc = scratch_for_current_device(&ws);
+        const int rc = scratch_for_stream_device((hipStream_t)stream, &ws);
         if (rc != RWK_OK) return rc;
     }
     return rwk_reduce_rows(in, p, v, out, ws, stream);

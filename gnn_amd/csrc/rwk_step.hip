@@ -140,7 +140,7 @@ struct SumAdamTail {
 };
 
 __global__ void __launch_bounds__(kBlock)
-hidden_backward_reduce_adam_kernel(const float *__restrict__ adj_hidden, const float *__restrict__ ah_in,
+hidden_backward_reduce_adam_kernel(const float *adj_hidden /* aliases a.param */, const float *__restrict__ ah_in,
                                    const float *__restrict__ z, const float *__restrict__ dz_partials, int n_partials,
                                    int n_hidden, int s, int d, int max_step, float *__restrict__ d_adj_hidden,
                                    float *__restrict__ d_feat_hidden, int n_slices, const float *__restrict__ red_in,

@@ -128,6 +128,7 @@ class DeviceDataset:
         if n_all and nonempty.any():
             self.graph_max_degree_h[nonempty] = np.maximum.reduceat(deg, node_ptr[:-1][nonempty])
         self.unit_values = bool(np.all(val == np.float32(1.0)))
+        self.y_h = y
         self.node_ptr = torch.from_numpy(node_ptr).to(dev)
         self.row_ptr = torch.from_numpy(row_ptr).to(dev)
         self.col = torch.from_numpy(col).to(dev)
@@ -202,7 +203,8 @@ class DeviceDataset:
                 raise ValueError("empty batch")
             # |column - first row of the row's 256-row block| must fit int16 for the compact columns
             fits16 = int(np.diff(table[0]).max()) + 255 <= 32767
-            metas.append((b, n, nnz, int(self.graph_max_degree_h[ids].max()), fits16, off))
+            yb = self.y_h[ids]
+            metas.append((b, n, nnz, int(self.graph_max_degree_h[ids].max()), fits16, off, int(yb.min()), int(yb.max())))
             tables.append(table.reshape(-1))
             off += table.size
         flat = np.concatenate(tables) if len(tables) > 1 else tables[0]
@@ -222,7 +224,7 @@ class DeviceDataset:
         from .structure import GraphStructure, register_structure
         lib = _lib.load()
         dev = self.device
-        b, n, nnz, max_degree, fits16, off = plan.metas[i]
+        b, n, nnz, max_degree, fits16, off, y_lo, y_hi = plan.metas[i]
         f = self.n_feat
         with _lib.device_guard(dev):
             if slot is None:
@@ -262,6 +264,7 @@ class DeviceDataset:
                 seg_ptr.data_ptr(), counts.data_ptr(), counts_f32.data_ptr(), _lib.current_stream(dev)),
                 "rwk_batch_build")
             adj = torch.sparse_coo_tensor(idx, vals, (n, n), check_invariants=False)
+            yy._rwk_label_range = (yy._version, y_lo, y_hi)      # known on the host (gnn_amd.head.check_labels)
             if self.symmetric:
                 st = GraphStructure.from_parts(dev, n, nnz, b, crow, col, val, col16, self.unit_values, max_degree,
                                                gid, seg_ptr, counts, counts_f32)

@@ -18,25 +18,25 @@ def head_supported(n_graphs: int, n_features: int, penultimate_dim: int, n_class
     return bool(_lib.load().rwk_head_supported(n_graphs, n_features, penultimate_dim, n_classes))
 
 
-_CHECKED_LABELS = {}
-
-
 def check_labels(labels, n_classes: int):
     """Class indices must lie in [0, n_classes), as ``F.cross_entropy`` requires (it raises otherwise; the kernels
-    would clamp silently).  One device-to-host read per label tensor: the result is remembered by tensor identity
-    and version, batches being reused every epoch (``rwgnn2/main.py:70-72``)."""
-    key = (labels.data_ptr(), labels._version, labels.numel(), int(n_classes))
-    if _CHECKED_LABELS.get(key):
-        return
-    if torch.cuda.is_current_stream_capturing():
-        return                                            # no host read under graph capture; warm-up steps came first
-    if labels.numel():
-        lo, hi = int(labels.min().item()), int(labels.max().item())
-        if lo < 0 or hi >= n_classes:
-            raise IndexError(f"Target {lo if lo < 0 else hi} is out of bounds for {n_classes} classes")
-    if len(_CHECKED_LABELS) > 4096:
-        _CHECKED_LABELS.clear()
-    _CHECKED_LABELS[key] = True
+    would clamp silently).  The range of a label tensor is read from the device once and kept ON the tensor object
+    (with the version it was read at), so it lives exactly as long as the tensor and is read again after an in-place
+    change; batches are reused every epoch (``rwgnn2/main.py:70-72``).  ``DeviceDataset.batch`` attaches the range of
+    the labels it gathered, which it knows on the host: streamed batches cost no device read."""
+    rng = getattr(labels, "_rwk_label_range", None)
+    if rng is None or rng[0] != labels._version:
+        if torch.cuda.is_current_stream_capturing():
+            return                                        # no host read under graph capture; warm-up steps came first
+        if labels.numel():
+            lo, hi = torch.stack(torch.aminmax(labels)).cpu().tolist()
+        else:
+            lo, hi = 0, 0
+        rng = (labels._version, int(lo), int(hi))
+        labels._rwk_label_range = rng
+    _, lo, hi = rng
+    if lo < 0 or hi >= n_classes:
+        raise IndexError(f"Target {lo if lo < 0 else hi} is out of bounds for {n_classes} classes")
 
 
 def _launch_forward(lib, kc, g, c, p, nc, bn_wc, bn_bc, running_mean, running_var, num_batches_tracked, momentum, eps,
@@ -244,19 +244,24 @@ class _FusedHeadLoss(torch.autograd.Function):
                 grads = torch.empty(lib.rwk_head_grad_size(c, p, nc), dtype=torch.float32, device=dev)
                 handoff = ctx.handoff
                 if (handoff is not None and handoff.get("fold_ok") and handoff.get("tail") is not None
-                        and ctx.needs_input_grad[0] and loss_partials is not None):
+                        and ctx.needs_input_grad[0] and loss_partials is not None
+                        and handoff["tail"].fold_allowed()):
                     # No launch here: the random-walk layer's backward (which runs next) forms d_k inside its fused
                     # kernel and sums the parameter gradients in the step's last launch (function.py, optim.StepTail).
-                    # `grads` is filled by that launch; d_k is never read there, dy stands in for its shape.
+                    # `grads` is filled by that launch, so autograd gets NO gradient for the six head parameters from
+                    # this node (it would copy, accumulate or hand to hooks a buffer nobody has written yet): the
+                    # step tail sets their .grad to views of `grads` once its launch is queued.  d_k is never read by
+                    # the layer's backward in this shape; dy stands in for its shape.
                     handoff["head_fold"] = {"k": kc, "dy": dy, "mean": mean, "invstd": invstd, "bn_w": bn_wc,
                                             "partials": partials, "d_loss": d_loss, "loss_partials": loss_partials,
                                             # detached: the loss with its grad_fn here would close a reference
                                             # cycle (node -> hand-off -> loss -> node) and keep this step's autograd
                                             # graph, AccumulateGrad nodes included, alive into the next step
                                             "loss": loss.detach(), "grads": grads,
-                                            "o_gamma": nc * p + nc + p * c + p}
+                                            "o_gamma": nc * p + nc + p * c + p,
+                                            "views": _split_grads(grads, c, p, nc)}
                     handoff["head_grads"] = (grads, c, p, nc)
-                    return (dy, None) + _split_grads(grads, c, p, nc) + (None,) * 10
+                    return (dy, None) + (None,) * 16
                 d_k = torch.empty((g, c), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
                 _lib.check(lib.rwk_head_train_backward(
                     kc.data_ptr(), g, c, p, nc, bn_wc.data_ptr(), mean.data_ptr(), invstd.data_ptr(), dy.data_ptr(),

@@ -91,7 +91,13 @@ class StepTail:
     dictionary, the head's backward leaves its gradient buffer there, and the layer's backward calls :meth:`launch`
     in place of ``rwk_hidden_backward_reduce``.  ``done`` then tells the trainer to skip ``optimizer.step()``.
     Requires the flat buffer to start with ``adj_hidden, features_hidden, fc.weight, fc.bias`` (``RW_NN``'s
-    parameter order) followed by the head's six tensors."""
+    parameter order) followed by the head's six tensors.
+
+    When the head's finishing launch is folded in as well (``head_fold``), the gradients of the head's six parameters
+    do not travel through autograd at all: this launch computes them, and :meth:`launch` then points the parameters'
+    ``.grad`` at them.  They are valid once that launch has run, i.e. for everything queued on the stream after the
+    backward pass - not inside tensor hooks of the backward pass itself, which is why the fold is taken only when
+    those parameters carry no hooks and no gradient to accumulate into (:meth:`fold_allowed`)."""
 
     def __init__(self, model, opt: FlatAdam, update: bool = True):
         self.opt = opt
@@ -131,6 +137,15 @@ class StepTail:
         self.counters = torch.zeros(max(n_counters, opt.step_counters.numel()), dtype=torch.int64, device=dev)
         self.counters.copy_(opt.step_counters[:1].expand_as(self.counters))
         opt.step_counters = self.counters
+
+    def fold_allowed(self) -> bool:
+        """The head's six parameters have nothing that would consume a gradient from autograd during the backward
+        pass: no ``.grad`` to accumulate into, no tensor hooks, no post-accumulate hooks."""
+        for p in self.opt.bucket.params[4:]:
+            if p.grad is not None or getattr(p, "_backward_hooks", None) \
+                    or getattr(p, "_post_accumulate_grad_hooks", None):
+                return False
+        return True
 
     def sync_counters(self):
         """After an update by the stand-alone Adam launch (which advances only its own workgroups' counters)."""
@@ -173,6 +188,10 @@ class StepTail:
         # the two launch shapes have different workgroup counts, each workgroup advancing its own counter: when the
         # shape changes, the counters the previous shape did not touch are brought along first
         upd = (lambda t: t.data_ptr()) if self.update else (lambda t: None)
+        # the handed-over bias corrections are those of one (beta1, beta2) pair: other betas start a fresh slot
+        if self.corr_slot is not None and getattr(self, "_slot_betas", o.betas) != o.betas:
+            self.corr_slot.zero_()
+        self._slot_betas = o.betas
         shape = "head" if head_fold is not None else "plain"
         if self.update and self._shape is not None and self._shape != shape:
             self.sync_counters()
@@ -190,6 +209,9 @@ class StepTail:
                 hp_.shape[1], head_fold["d_loss"].data_ptr(), head_fold["grads"].data_ptr(),
                 head_fold["loss_partials"].data_ptr(), head_fold["loss"].data_ptr(), int(n_graphs), stream),
                 "rwk_hidden_backward_reduce_adam_head")
+            # autograd handed these six parameters nothing (head.py): their gradients are what this launch writes
+            for prm, view in zip(self.opt.bucket.params[4:], head_fold["views"]):
+                prm.grad = view
             self.head_folds += 1
             self.done = True
             return

@@ -11,6 +11,9 @@ fresh masks.
 """
 from __future__ import annotations
 
+import contextlib
+import warnings
+
 import torch
 import torch.nn.functional as F
 
@@ -18,7 +21,36 @@ from .dp import FlatGradBucket
 from .losses import cross_entropy
 from .optim import FlatAdam, StepTail
 
-__all__ = ["Trainer", "EpochTrainer", "StreamTrainer"]
+__all__ = ["Trainer", "EpochTrainer", "StreamTrainer", "stale_autograd_graph_is_an_error"]
+
+_STALE_MESSAGE = "The AccumulateGrad node's stream does not match"
+
+
+@contextlib.contextmanager
+def stale_autograd_graph_is_an_error():
+    """Inside this block, a backward pass that meets ``AccumulateGrad`` nodes created on another stream raises
+    ``RuntimeError`` instead of torch's warn-once message.  Such nodes survive only while something still refers to an
+    earlier step's autograd graph (a kept ``loss``, for instance).  They are harmless to an eager step, but they fork
+    a backward pass that is being captured over two streams, and ending such a capture has crashed the process
+    (a segmentation fault inside ``capture_end``, not an exception).  ``Trainer.capture`` therefore runs its warm-up
+    steps - on a side stream, like the capture itself - and the capture under this check: a graph that is still
+    alive is reported by the first warm-up step, before any capture has begun."""
+    prev = torch.is_warn_always_enabled()
+    torch.set_warn_always(True)              # the message is a warn-once: make every occurrence count
+    try:
+        with warnings.catch_warnings():
+            warnings.filterwarnings("error", message=_STALE_MESSAGE)
+            yield
+    except UserWarning as w:
+        if _STALE_MESSAGE not in str(w):
+            raise
+        raise RuntimeError(
+            "an autograd graph of an earlier step is still alive (is a loss tensor of an earlier step, or anything "
+            "else with a grad_fn that reaches the parameters, still referenced?): its AccumulateGrad nodes belong to "
+            "another stream and would fork the captured backward pass over two streams; drop the reference "
+            "(or .detach() what is kept) and capture again") from w
+    finally:
+        torch.set_warn_always(prev)
 
 
 class Trainer:
@@ -86,6 +118,9 @@ class Trainer:
         self._single_loss = None
 
     def fwd_bwd(self):
+        # the previous step's autograd graph goes first: while it lives, so do its AccumulateGrad nodes, and the new
+        # forward would reuse them, whatever stream they were created on
+        self.loss = None
         self.bucket.release()            # optimizer.zero_grad(set_to_none=True)
         if self.tail is not None:
             self.tail.armed = True       # this backward pass ends with the optimiser's update
@@ -141,24 +176,27 @@ class Trainer:
         device, so the result is the same as that many single-step replays."""
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
+        # Warm-up on a side stream, under the stale-graph check: an autograd graph of an earlier step that something
+        # still refers to raises here, before any capture has begun (see stale_autograd_graph_is_an_error).
+        with torch.cuda.stream(s), stale_autograd_graph_is_an_error():
             for _ in range(3):
                 self.step_eager()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         # Drop the warm-up's autograd graph before capturing: its AccumulateGrad nodes are bound to the warm-up
-        # stream, and reusing them would fork the captured backward over two streams (torch warns about it; the
-        # forked replay was seen to feed stale gradients to the random-walk layer).
+        # stream, and reusing them would fork the captured backward over two streams (the forked replay was seen to
+        # feed stale gradients to the random-walk layer, and ending such a capture to crash the process).
         self.loss = None
         if self.world > 1 and self.capture_collective and not self.sync_before_all_reduce:
             if self._capture_single_graph():
                 return
         self.collective_captured = False
         self.g_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fb, capture_error_mode=self.capture_error_mode):
-            self.fwd_bwd()
-            if self.world == 1:          # nothing happens between backward and the update: one graph
-                self._opt_step()
+        with stale_autograd_graph_is_an_error():
+            with torch.cuda.graph(self.g_fb, capture_error_mode=self.capture_error_mode):
+                self.fwd_bwd()
+                if self.world == 1:          # nothing happens between backward and the update: one graph
+                    self._opt_step()
         self._single_loss = self.loss = self.loss.detach()   # same storage, without the captured autograd graph
         if self.world > 1:
             # The flat Adam update is ONE launch: as a graph of its own it would pay a replay's start (7.5 us) for a
@@ -322,14 +360,15 @@ class EpochTrainer(Trainer):
     def capture_epoch(self):
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
+        with torch.cuda.stream(s), stale_autograd_graph_is_an_error():
             self.epoch_eager()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.loss = None                  # drop the warm-up's autograd graph (see Trainer.capture)
         self.g_epoch = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_epoch, capture_error_mode=self.capture_error_mode):
-            self.epoch_losses = self._epoch()
+        with stale_autograd_graph_is_an_error():
+            with torch.cuda.graph(self.g_epoch, capture_error_mode=self.capture_error_mode):
+                self.epoch_losses = self._epoch()
         self.loss = self.epoch_losses[-1]
 
     def run_epoch(self):

@@ -39,6 +39,7 @@ extern "C" {
 #define RWK_E_UNSUPPORTED (-3) /* hyper-parameters outside what the kernels are built for */
 #define RWK_E_ALIGN (-4)       /* a pointer is not aligned as documented */
 #define RWK_E_STATIC_SIZE (-5) /* the input needs more of the library's fixed device scratch than it holds */
+#define RWK_E_DEVICE (-6)      /* the stream's device is not the current device */
 
 typedef void *rwk_stream_t;
 
@@ -476,7 +477,8 @@ int rwk_hidden_backward_reduce(const float *adj_hidden, const float *ah, const f
  * rwk_adam_step follow.  corr_slot (may be NULL): four int64 of device memory, zeroed once, that the launches of
  * consecutive steps hand Adam's two bias corrections through: the column-sum workgroup, which ends early, computes the
  * next step's pair (double-precision power loops and a root, 0.6 us in one thread) so that the next launch's
- * workgroups need not; a slot whose step count does not match is ignored. */
+ * workgroups need not; a slot whose step count does not match is ignored.  The slot does not record beta1 / beta2:
+ * it belongs to ONE optimiser with fixed betas - zero it when the betas change, never share it. */
 int64_t rwk_step_tail_n_counters(int64_t h, int64_t n, int64_t rest_off);
 int rwk_hidden_backward_reduce_adam(const float *adj_hidden, const float *ah, const float *z, const float *dz_partials,
                                     int64_t n_partials, int64_t h, int64_t s, int64_t d, int64_t max_step,
@@ -529,7 +531,9 @@ int rwk_reduce_rows_to32(const float *in, int64_t p, int64_t v, float *out32, rw
  * instead of a caller-owned workspace.  v above that limit (when a workspace is needed at all, i.e. p > 32 and
  * (v > 64 or p > 2^20)) returns RWK_E_STATIC_SIZE.  Calls no hipMalloc / hipFree.  All calls on one GPU share that
  * GPU's array: calls that overlap on one GPU (different streams, or different host threads without stream
- * order between them) race. */
+ * order between them) race.  The device that owns `stream` must be the current device (RWK_E_DEVICE otherwise: every
+ * GPU has its own copy of the array at its own address).  The first call on a device looks that address up
+ * (hipGetSymbolAddress); under graph capture, make one call per device before the capture begins. */
 #define RWK_REDUCE_ROWS_STATIC_MAX_V 16384
 int rwk_reduce_rows_static(const float *in, int64_t p, int64_t v, float *out, rwk_stream_t stream);
 

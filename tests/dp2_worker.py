@@ -95,7 +95,7 @@ def main(outdir):
             dist.all_gather(both, mine)
             same = same and all(torch.equal(both[0], x) for x in both[1:])
         result["params_bit_identical"] = bool(same)
-        result["finite"] = bool(torch.isfinite(tr.opt.flat_param).all()) and np.isfinite(result["loss"])
+        result["finite"] = bool(torch.isfinite(tr.opt.flat_param).all()) and bool(np.isfinite(result["loss"]))
         result["steps"] = int(tr.opt.step_counters[0])
         result["ok"] = bool(layer_ok and same and result["finite"] and result["steps"] == 3 + 3 + 2)
         dist.barrier()

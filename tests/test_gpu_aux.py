@@ -387,3 +387,23 @@ def test_fused_loss_is_nan_until_backward_and_labels_are_checked(dev):
     bad[3] = -100
     with pytest.raises(IndexError):
         m.forward_with_loss(adj, feats, gi, bad)
+
+
+def test_capture_refuses_a_leaked_autograd_graph(dev):
+    """A reference to an earlier step's loss keeps that step's autograd graph, and with it AccumulateGrad nodes bound
+    to the stream it ran on, alive; a backward pass captured in that state is forked over two streams (ending such a
+    capture has crashed the process).  Trainer.capture reports it as a RuntimeError from its first warm-up step,
+    before any capture begins; once the reference is gone the capture goes through."""
+    c = GoldenCase("mutag_b0")
+    tr = _trainer(c, dict(c.hp, dropout=0.0), dev)
+    tr.step_eager()
+    leaked = tr.loss
+    assert leaked.grad_fn is not None
+    with pytest.raises(RuntimeError, match="still alive"):
+        tr.capture()
+    assert tr.g_fb is None
+    del leaked
+    tr.capture()
+    tr.step_graph()
+    torch.cuda.synchronize()
+    assert np.isfinite(float(tr.loss))

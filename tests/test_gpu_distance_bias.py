@@ -152,3 +152,43 @@ def test_full_size_properties(dev):
         by_col = torch.bincount(st.col[sel].long(), minlength=n)
         assert torch.equal(by_row, by_col)
         assert torch.equal(by_row, lc[:, d - 1])
+
+
+@pytest.mark.parametrize("name", ["cora", "pubmed"])
+def test_planetoid_scale_single_graph(dev, name):
+    """The operator on the Cora- and PubMed-shaped graphs (2708 / 19 717 nodes, 10 556 / 88 648 stored entries, one
+    graph): rows of P x for a sample of source nodes against P rows built from scipy's hop-limited shortest paths
+    (the reference's other route to the distance matrix, rwgnn2/rwgnn_dis_bias6.py:130-154) in float64 - the dense
+    all-pairs restatement is 3 GB at PubMed's size -, plus the properties that need no matrix."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import dijkstra
+    from gnn_amd.distance_bias import distance_bias_propagate, distance_bias_structure
+    from gnn_amd.synth import config_batch
+    b = config_batch(name, 1)
+    adj, feats, gi, y = b.to_torch(dev)
+    n = b.n_nodes
+    max_distance, alpha, c = 3, 1.0, 0.1
+    st = distance_bias_structure(adj, gi, max_distance=max_distance, walk_type="exp", alpha=alpha, c=c)
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    x = torch.randn(n, 8, generator=gen).to(dev).requires_grad_(True)
+    g = torch.randn(n, 8, generator=gen).to(dev)
+    out = distance_bias_propagate(x, st)
+    out.backward(g)
+    a = csr_matrix((b.values, (b.indices[0], b.indices[1])), shape=(n, n))
+    sample = np.random.default_rng(2).choice(n, size=64, replace=False)
+    dist = dijkstra(a, directed=False, indices=sample, unweighted=True, limit=max_distance)
+    dist[np.isinf(dist)] = max_distance + 1
+    w = np.exp(-alpha * dist)
+    w[np.arange(sample.size), sample] = 0.0
+    rs = w.sum(axis=1, keepdims=True)
+    rs[rs == 0] = 1
+    x64 = x.detach().cpu().numpy().astype(np.float64)
+    want = (1 - c) * (w / rs) @ x64 + c / n * x64.sum(axis=0, keepdims=True)
+    got = out.detach().cpu().numpy()[sample]
+    assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+    ones = torch.ones(n, 2, device=dev)
+    assert float((distance_bias_propagate(ones, st) - 1.0).abs().max()) < 1e-5
+    lhs = float((out.detach().double() * g.double()).sum())
+    rhs = float((x.detach().double() * x.grad.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0)
+    assert torch.equal(st.level_count.long()[:, 0], (st.base.csr.crow[1:] - st.base.csr.crow[:-1]).long())

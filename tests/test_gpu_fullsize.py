@@ -108,12 +108,15 @@ def test_backward_full_size_against_oracle_vjp(name, n_graphs, dev):
     assert rel(got["features"].cpu().numpy(), want.pop("features")) < TOL
     check_gradients(got, want, b.n_nodes, {"fc.bias": np.abs(d_pre).max(),
                                            "fc.weight": np.abs(d_pre).max() * np.abs(f64).max()})
-    # bitwise reproducibility of the backward at full size
+    # bitwise reproducibility of the backward at full size: the hidden-graph gradients (fixed-order reductions) and
+    # the per-node input gradient (on the matrix-core path the tensor the later hidden-graph blocks add to at the L2)
     g1 = m.features_hidden.grad.clone()
+    f1 = feats.grad.clone()
     m.zero_grad()
     feats.grad = None
     m.rw_features(adj, feats, gi).backward(torch.from_numpy(dk).to(dev))
     assert torch.equal(g1, m.features_hidden.grad)
+    assert torch.equal(f1, feats.grad)
 
 
 def test_graph_permutation_invariance_full_size(dev):

@@ -1,6 +1,7 @@
 """``rwk_reduce_rows_static`` (the entry point that allocates nothing) against ``rwk_reduce_rows`` with a caller-owned
 workspace: same bits, on two calls in a row, the second with a smaller input (the library's fixed device scratch
-keeps the first call's contents), plus the size limit.  Runs last in the suite and alone in a fresh process."""
+keeps the first call's contents), the size limit, and a call recorded in a HIP graph.  Collected last, so it runs
+after every other test of the suite in the same process; it also passes when this file is run on its own."""
 import numpy as np
 import pytest
 import torch
@@ -63,3 +64,25 @@ def test_static_scratch_limit_is_reported(dev):
     _lib.check(lib.rwk_reduce_rows_static(x.data_ptr(), 40, 16384, out.data_ptr(), _lib.current_stream(dev)), "static")
     torch.cuda.synchronize()
     assert bool((out == 40.0).all())
+
+
+def test_static_scratch_call_inside_a_captured_graph(dev):
+    """After one call outside (the per-device address lookup), the entry point is recorded into a HIP graph and
+    replayed on new contents of the same input buffer: same bits as the workspace entry point."""
+    from gnn_amd import _lib
+    lib = _lib.load()
+    p, v = 300, 700
+    x = torch.randn(p, v, device=dev)
+    got = torch.zeros(v, device=dev)
+    _lib.check(lib.rwk_reduce_rows_static(x.data_ptr(), p, v, got.data_ptr(), _lib.current_stream(dev)), "warm-up")
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        _lib.check(lib.rwk_reduce_rows_static(x.data_ptr(), p, v, got.data_ptr(), _lib.current_stream(dev)),
+                   "rwk_reduce_rows_static under capture")
+    for seed in (1, 2):
+        x.copy_(torch.randn(p, v, generator=torch.Generator().manual_seed(seed)))
+        g.replay()
+        torch.cuda.synchronize()
+        want, _, _ = _both(lib, _lib, x, dev)
+        assert torch.equal(want, got)
