@@ -22,8 +22,15 @@
 static inline int64_t rwk_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---------------------------------------------------------------------------------------
-// Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3").
+// Philox4x32-R (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3").  The paper's default is
+// ten rounds; seven is the smallest round count it reports as passing the whole BigCrush battery.  The head's
+// dropout (G x P samples per step) uses ten.  The random-walk layer's mask - one call per (node, hidden graph) and
+// step of training, a third of the vector instructions of the fused kernels at ten rounds - uses seven
+// (RWK_MASK_ROUNDS); tests/test_oracle_golden.py holds the known-answer vectors of both and the statistics of the
+// resulting keep mask (rates and pairwise correlations within five standard deviations on 10^7 samples).
 // ---------------------------------------------------------------------------------------
+#define RWK_MASK_ROUNDS 7
+
 struct RwkPhilox4 {
     uint32_t x, y, z, w;
 };
@@ -37,10 +44,11 @@ __host__ __device__ static inline uint32_t rwk_xor3(uint32_t a, uint32_t b, uint
 #endif
 }
 
-__host__ __device__ static inline RwkPhilox4 rwk_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
-                                                               uint32_t c3, uint32_t k0, uint32_t k1) {
+template <int ROUNDS>
+__host__ __device__ static inline RwkPhilox4 rwk_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                            uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t n0 = rwk_xor3((uint32_t)(p1 >> 32), c1, k0);
@@ -54,10 +62,21 @@ __host__ __device__ static inline RwkPhilox4 rwk_philox4x32_10(uint32_t c0, uint
     return RwkPhilox4{c0, c1, c2, c3};
 }
 
+__host__ __device__ static inline RwkPhilox4 rwk_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
+                                                               uint32_t c3, uint32_t k0, uint32_t k1) {
+    return rwk_philox4x32<10>(c0, c1, c2, c3, k0, k1);
+}
+
+// the random-walk layer's mask generator
+__host__ __device__ static inline RwkPhilox4 rwk_philox_mask(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                             uint32_t k0, uint32_t k1) {
+    return rwk_philox4x32<RWK_MASK_ROUNDS>(c0, c1, c2, c3, k0, k1);
+}
+
 // Dropout keep-mask specification (shared by forward, backward, the mask dump and the oracle):
 //   one Philox stream per (node n, hidden graph h); element (step i, hidden node s) is sample
 //   e = s*L + i of that stream; sample e is byte (e % 15) of call (e / 15), where a call is
-//   philox4x32_10(counter = {n, h, call, offset_lo}, key = {seed_lo, seed_hi ^ offset_hi}) and byte j
+//   philox4x32 with RWK_MASK_ROUNDS rounds (counter = {n, h, call, offset_lo}, key = {seed_lo, seed_hi ^ offset_hi}) and byte j
 //   is bits [8*(j&3), 8*(j&3)+8) of output word j>>2.  Byte 15 of the call breaks ties:
 //   keep <=> b < T0 || (b == T0 && byte15 < T1), with T0 = floor(q*256), T1 = floor((q*256-T0)*256),
 //   q = 1 - p: the keep probability is q rounded down to a multiple of 2^-16.
@@ -83,7 +102,7 @@ static inline void rwk_drop_thresholds(float drop_p, uint32_t *t0, uint32_t *t1)
 
 // 15 keep bits (bit j <-> byte j) of one call.
 __device__ static inline uint32_t rwk_keep_bits15(const RwkDropCfg &cfg, uint32_t n, uint32_t h, uint32_t call) {
-    const RwkPhilox4 r = rwk_philox4x32_10(n, h, call, cfg.off_lo, cfg.seed_lo, cfg.key_hi);
+    const RwkPhilox4 r = rwk_philox_mask(n, h, call, cfg.off_lo, cfg.seed_lo, cfg.key_hi);
     const uint32_t tie = (r.w >> 24) < cfg.t1 ? 1u : 0u;
     const uint32_t w[4] = {r.x, r.y, r.z, r.w};
     uint32_t bits = 0;

@@ -49,7 +49,7 @@ __device__ inline unsigned long long keep_bits(const DropCfg &c, uint32_t node, 
 #pragma unroll
     for (int call = 0; call < 3; ++call) {
         if (call < n_calls) {
-            const RwkPhilox4 r = rwk_philox4x32_10(node, hq, (uint32_t)call, c.off_lo, c.seed_lo, c.key_hi);
+            const RwkPhilox4 r = rwk_philox_mask(node, hq, (uint32_t)call, c.off_lo, c.seed_lo, c.key_hi);
             const uint32_t thr = c.t0 + ((r.w >> 24) < c.t1 ? 1u : 0u);
             const uint32_t w[4] = {r.x, r.y, r.z, r.w};
             uint32_t m = 0;

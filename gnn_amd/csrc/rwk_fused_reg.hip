@@ -5,7 +5,7 @@
 // size S and the step count L are template parameters, so
 //   * the lane's L*S rows of Z live in registers for the whole kernel (no LDS reads in the loop),
 //   * the gradient of Z accumulates in L*S*4 registers per lane (no LDS read-modify-write per node),
-//   * every dropout sample index is a compile-time constant: one Philox4x32-10 call per 15 samples,
+//   * every dropout sample index is a compile-time constant: one Philox4x32-7 call per 15 samples,
 //     each sample one byte compare.
 // LDS is touched once, at the end of the backward kernel, to add the lanes that own the same hidden
 // graph in a fixed order.
@@ -81,7 +81,7 @@ struct Keep {
     __device__ inline void draw(const DropCfg &c, uint32_t node, uint32_t hq) {
 #pragma unroll
         for (int call = 0; call < NC; ++call) {
-            const RwkPhilox4 r = rwk_philox4x32_10(node, hq, (uint32_t)call, c.off_lo, c.seed_lo, c.key_hi);
+            const RwkPhilox4 r = rwk_philox_mask(node, hq, (uint32_t)call, c.off_lo, c.seed_lo, c.key_hi);
             w[call][0] = r.x; w[call][1] = r.y; w[call][2] = r.z; w[call][3] = r.w;
             thr[call] = c.t0 + ((r.w >> 24) < c.t1 ? 1u : 0u);
         }

@@ -182,7 +182,7 @@ int rwk_hidden_backward(const float *adj_hidden, const float *ah, const float *z
  *   K[g, i*H+h] = c_g * sum_{p in g} sum_s m[i,h,s,n] * (Z0[h,s].X0[n]) * (Zi[h,s].Xi[n])
  *
  * The (H*S) x N products never leave registers.  Dropout (model.py:58) is a counter-based
- * Philox4x32-10 mask regenerated identically in backward from rng (uint64[2] {seed,offset},
+ * Philox4x32-7 mask regenerated identically in backward from rng (uint64[2] {seed,offset},
  * device memory; NULL or drop_p == 0 means no dropout).
  *
  * Work split: "streams" of `stream_len` consecutive sorted positions; stream c covers

@@ -19,7 +19,7 @@ What is restated (citations are to ``/root/reference/rwgnn2/model.py``, identica
                              sum over hidden nodes, normalisation, concatenation)
 * ``rw_kernel_backward``  -- the analytic vector-Jacobian product of the same lines
 * ``rw_kernel_gram``      -- an independent closed form, valid without dropout
-* ``philox4x32_10`` / ``dropout_keep``  -- the counter-based dropout mask the HIP kernels
+* ``philox4x32`` / ``dropout_keep``  -- the counter-based dropout mask the HIP kernels
                              generate, so a masked forward/backward can be replayed here.
 """
 from __future__ import annotations
@@ -246,7 +246,7 @@ def rw_kernel_gram(csr, x0, adj_hidden, features_hidden, graph_indicator, max_st
 
 
 # --------------------------------------------------------------------------------------
-# counter-based dropout mask (restates gnn_amd/csrc/rwk_philox.h so masks can be replayed)
+# counter-based dropout mask (restates gnn_amd/csrc/rwk_common.h so masks can be replayed)
 # --------------------------------------------------------------------------------------
 
 _PHILOX_M0 = np.uint64(0xD2511F53)
@@ -255,8 +255,17 @@ _PHILOX_W0 = np.uint32(0x9E3779B9)
 _PHILOX_W1 = np.uint32(0xBB67AE85)
 
 
+#: rounds of the random-walk layer's mask generator (gnn_amd/csrc/rwk_common.h: RWK_MASK_ROUNDS)
+MASK_ROUNDS = 7
+
+
 def philox4x32_10(c0, c1, c2, c3, k0, k1):
-    """Philox4x32 with 10 rounds (Salmon et al., SC'11); all arguments uint32 arrays
+    """Philox4x32 with the paper's default 10 rounds."""
+    return philox4x32(c0, c1, c2, c3, k0, k1, 10)
+
+
+def philox4x32(c0, c1, c2, c3, k0, k1, rounds):
+    """Philox4x32 with ``rounds`` rounds (Salmon et al., SC'11); all arguments uint32 arrays
     (broadcastable).  Returns four uint32 arrays."""
     c0, c1, c2, c3 = (np.asarray(v, np.uint32) for v in (c0, c1, c2, c3))
     c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
@@ -264,7 +273,7 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     k1 = np.uint32(k1)
     mask32 = np.uint64(0xFFFFFFFF)
     with np.errstate(over="ignore"):
-        for _ in range(10):
+        for _ in range(rounds):
             p0 = _PHILOX_M0 * c0.astype(np.uint64)
             p1 = _PHILOX_M1 * c2.astype(np.uint64)
             hi0 = (p0 >> np.uint64(32)).astype(np.uint32)
@@ -290,7 +299,7 @@ def dropout_keep(seed: int, offset: int, n_nodes: int, h: int, s: int, max_step:
     """Boolean keep-mask (max_step, H, S, N) exactly as the HIP kernels draw it
     (specification in gnn_amd/csrc/rwk_common.h).
 
-    One Philox4x32-10 stream per (node n, hidden graph h): call c has counter
+    One Philox4x32-7 stream (``MASK_ROUNDS``) per (node n, hidden graph h): call c has counter
     (n, h, c, offset_lo) and key (seed_lo, seed_hi ^ offset_hi).  Element (step i, hidden node s)
     is sample e = s*L + i: byte (e % 15) of call (e // 15), byte j being bits [8(j&3), 8(j&3)+8) of
     output word j>>2.  Byte 15 of each call breaks ties.
@@ -306,7 +315,7 @@ def dropout_keep(seed: int, offset: int, n_nodes: int, h: int, s: int, max_step:
     off_hi = np.uint32((offset >> 32) & 0xFFFFFFFF)
     k0 = np.uint32(seed & 0xFFFFFFFF)
     k1 = np.uint32((seed >> 32) & 0xFFFFFFFF) ^ off_hi
-    w = philox4x32_10(nn + zero, hh + zero, cc + zero, off_lo + zero, k0, k1)
+    w = philox4x32(nn + zero, hh + zero, cc + zero, off_lo + zero, k0, k1, MASK_ROUNDS)
     words = np.stack(w, axis=-1)                                   # (H, N, calls, 4)
     shifts = np.array([0, 8, 16, 24], dtype=np.uint32)
     by = ((words[..., :, None] >> shifts) & np.uint32(0xFF)).reshape(h, n_nodes, n_calls, 16)

@@ -142,6 +142,46 @@ def test_philox_known_answers():
     assert [int(v) for v in r] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     r = O.philox4x32_10(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0)
     assert [int(v) for v in r] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    # ... and for Philox4x32-7, the round count of the random-walk layer's mask
+    assert O.MASK_ROUNDS == 7
+    r = O.philox4x32(0, 0, 0, 0, 0, 0, 7)
+    assert [int(v) for v in r] == [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]
+    r = O.philox4x32(0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 7)
+    assert [int(v) for v in r] == [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]
+    r = O.philox4x32(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0, 7)
+    assert [int(v) for v in r] == [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]
+
+
+def test_dropout_mask_rates_and_correlations_on_ten_million_samples():
+    """The keep mask of the default shape (two steps, five hidden nodes, sixteen hidden graphs) over 62 500 nodes =
+    10^7 samples: the keep rate of every (step, hidden node) plane within five standard deviations of the
+    specification's probability, and the correlation of neighbouring samples along every axis (step, hidden node,
+    hidden graph, node) - the pairs that share a generator call, a counter word or consecutive counters - within
+    five standard deviations of zero."""
+    p = 0.2
+    keep = O.dropout_keep(seed=0x1234567, offset=99, n_nodes=62500, h=16, s=5, max_step=2, drop_p=p)
+    assert keep.size == 10 ** 7
+    t0, t1 = O.dropout_thresholds(p)
+    q = (t0 + t1 / 256.0) / 256.0
+    assert abs(q - (1 - p)) < 2.0 ** -16
+    x = keep.astype(np.float64)                                   # (L, H, S, N)
+    var = q * (1 - q)
+    for i in range(2):
+        for s in range(5):
+            plane = x[i, :, s, :]
+            assert abs(plane.mean() - q) < 5 * np.sqrt(var / plane.size), (i, s)
+
+    def corr(a, b):
+        return ((a - q) * (b - q)).mean() / var
+
+    pairs = {"step": (x[0], x[1]), "hidden node": (x[:, :, :-1], x[:, :, 1:]), "hidden graph": (x[:, :-1], x[:, 1:]),
+             "node": (x[..., :-1], x[..., 1:]), "node + 2": (x[..., :-2], x[..., 2:]),
+             "hidden node + 2": (x[:, :, :-2], x[:, :, 2:])}
+    for name, (a, b) in pairs.items():
+        assert abs(corr(a, b)) < 5 / np.sqrt(a.size), name
+    # the same counters under another key: an independent mask
+    other = O.dropout_keep(seed=0x1234568, offset=99, n_nodes=62500, h=16, s=5, max_step=2, drop_p=p)
+    assert abs(corr(x, other.astype(np.float64))) < 5 / np.sqrt(x.size)
 
 
 def test_dropout_mask_statistics_and_replay():
