@@ -111,6 +111,12 @@ SIGNATURES = {
     "rwk_reduce_rows_level1": (_I64, [_I64]),
     "rwk_reduce_rows_to32": (c_int, [_P, _I64, _I64, _P, _P]),
     "rwk_reduce_rows_static": (c_int, [_P, _I64, _I64, _P, _P]),
+    "rwk_gram_supported": (c_int, [_I64, _I64, _I64, _I64]),
+    "rwk_gram_forward": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_int, _P, _P, _P]),
+    "rwk_gram_backward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_int, _P, _P, _P]),
+    "rwk_eval_forward_lds": (_I64, [_I64] * 8),
+    "rwk_eval_forward": (c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64,
+                                 c_int, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "rwk_gather_chunks": (c_int, [_P, _P, _I64, _P, _P]),
     "rwk_adam_n_counters": (_I64, [_I64]),
     "rwk_adam_step": (c_int, [_P, _P, _P, _P, _I64, _P, c_float, c_float, c_float, c_float, _P, _P]),

@@ -1,0 +1,371 @@
+// RW_NN.forward in evaluation mode (rwgnn2/model.py:31-72 under model.eval(): no dropout, batch-norm on its running
+// statistics) as ONE launch, one workgroup per graph.
+//
+// A batch is block-diagonal: every neighbour of a node lies in the node's own graph.  Without dropout the layer
+// factorises through the graph's Gram matrices (rwk_gram.hip), and an evaluation-mode head treats every row of K on
+// its own.  So the workgroup of graph g can do everything for g without leaving the chip: project its nodes
+// (X0 = sigmoid(features W^T + b), model.py:43) into LDS, propagate them there (X_i = A X_{i-1}, model.py:55, the
+// graph's CSR rows gathered from LDS), build the hidden graphs' Z_i = Ah^i Z0 (model.py:39-42,56; a few thousand
+// multiply-adds, recomputed per workgroup), form C[g,i] = sum_n X0[n] (x) X_i[n] and K[g, i*H+h] = sum_s Z0[h,s]^T
+// C[g,i] Z_i[h,s] (model.py:45-67), and run the head on that one row (model.py:68-72).  The reference's validation and
+// test loops (rwgnn2/main.py:110-117,148-151) call exactly this every epoch; as separate launches (projection +
+// hidden graphs, SpMM, Gram, head) it took 28 us on 1024 graphs of 300 nodes, of which 20 were launch boundaries and
+// dependent round trips of four tiny kernels.
+//
+// hidden_dim <= 4; graphs of at most max_nodes nodes, with everything fitting the LDS budget (rwk_eval_forward_lds).
+// Same operations in the same order as the stand-alone kernels where that is cheap (projection, hidden-graph chain,
+// neighbour sums in stored order); all sums in fixed orders: bitwise reproducible.
+#include "rwk_common.h"
+#include "rwk_hidden_body.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / RWK_WAVE;
+constexpr int kSlots = kBlock / 4;
+constexpr size_t kLdsBudget = 150 * 1024;
+
+struct EvalArgs {
+    const float *feat;        // (n, f) raw features, or (n, d) pre-activations when fc_w is null
+    int f;
+    const float *fc_w, *fc_b;
+    const float *adj_hidden, *feat_hidden;
+    const int *crow, *col;
+    const float *val;         // null: every stored value is 1
+    const int *seg_ptr;
+    const float *counts_f32;
+    int n, d, h, s, normalize, max_nodes;
+    const float *bn_w, *bn_b, *rmean, *rvar;
+    float eps;
+    const float *w1, *b1, *w2, *b2;
+    int p, nc;
+    float *k_out, *out;
+};
+
+__device__ inline float pick4(const float4 &v, int a) { return a == 0 ? v.x : a == 1 ? v.y : a == 2 ? v.z : v.w; }
+
+__device__ inline float slot_sum16(float v) {
+    v += __shfl_xor(v, 4, RWK_WAVE);
+    v += __shfl_xor(v, 8, RWK_WAVE);
+    v += __shfl_xor(v, 16, RWK_WAVE);
+    v += __shfl_xor(v, 32, RWK_WAVE);
+    return v;
+}
+
+template <int LT>
+__global__ void __launch_bounds__(kBlock) eval_forward_kernel(const EvalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int h = a.h, s = a.s, d = a.d;
+    float *zs = lds;                                   // [LT][h][s][4]
+    float *xs = zs + LT * h * s * 4;                   // [LT][max_nodes][4]  (16-byte rows: before the odd-sized ah)
+    float *ah = xs + (size_t)LT * a.max_nodes * 4;     // [h][s][s]
+    float *part = ah + h * s * s;                      // [kWaves][LT][16]
+    float *cm = part + kWaves * LT * 16;               // [LT][16]
+    float *krow = cm + LT * 16;                        // [LT * h]
+    float *h1 = krow + LT * h;                         // [p]
+    float *o = h1 + a.p;                               // [nc]
+    float *bn = o + a.nc;                              // [4][LT * h]: running mean, running var, gamma, beta
+    float *w1s = bn + 4 * LT * h;                      // [p][LT * h]
+    float *b1s = w1s + (size_t)a.p * LT * h;           // [p]
+    float *w2s = b1s + a.p;                            // [nc][p]
+    float *b2s = w2s + (size_t)a.nc * a.p;             // [nc]
+    float *fcs = b2s + a.nc;                           // [d * f + d]: projection weights and bias
+    const int tid = threadIdx.x;
+    const int g = blockIdx.x;
+    const int p0 = a.seg_ptr[g], ng = a.seg_ptr[g + 1] - p0;
+
+    // ---- hidden graphs: Ah = sym(triu(relu(adj_hidden))), Z_i = Ah Z_{i-1}
+    const int n_pairs = s * (s - 1) / 2;
+    for (int i = tid; i < h * s * s; i += kBlock) ah[i] = 0.f;
+    for (int i = tid; i < h * s * 4; i += kBlock) {
+        const int k = i & 3, r = i >> 2;               // r = hh * s + ss
+        zs[i] = k < d ? a.feat_hidden[(size_t)r * d + k] : 0.f;
+    }
+    // row pointers of this thread's first two nodes: requested now, used after the projection (the thread that
+    // projects node p0 + tid (+ 256) is the one that later gathers its neighbours)
+    int e_beg[2] = {0, 0}, e_end[2] = {0, 0};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int local = tid + r * kBlock;
+        if (local < ng) {
+            e_beg[r] = a.crow[p0 + local];
+            e_end[r] = a.crow[p0 + local + 1];
+        }
+    }
+    if (a.fc_w != nullptr)
+        for (int i = tid; i < d * a.f + d; i += kBlock) fcs[i] = i < d * a.f ? a.fc_w[i] : a.fc_b[i - d * a.f];
+    if (a.out != nullptr) {
+        // the head's parameters travel to LDS now, with every other first load of the workgroup: read where they are
+        // used (row j of fc1 by thread j, one element per step of its sum) they cost a trip to the L2 per element
+        const int lh0 = LT * h;
+        for (int i = tid; i < lh0; i += kBlock) {
+            bn[i] = a.rmean[i];
+            bn[lh0 + i] = a.rvar[i];
+            bn[2 * lh0 + i] = a.bn_w[i];
+            bn[3 * lh0 + i] = a.bn_b[i];
+        }
+        for (int i = tid; i < a.p * lh0; i += kBlock) w1s[i] = a.w1[i];
+        for (int i = tid; i < a.p; i += kBlock) b1s[i] = a.b1[i];
+        for (int i = tid; i < a.nc * a.p; i += kBlock) w2s[i] = a.w2[i];
+        for (int i = tid; i < a.nc; i += kBlock) b2s[i] = a.b2[i];
+    }
+    __syncthreads();
+    for (int i = tid; i < h * n_pairs; i += kBlock) {
+        const int hh = i / n_pairs, k = i - hh * n_pairs;
+        int r, c;
+        triu_pair(k, s, &r, &c);
+        const float w = fmaxf(a.adj_hidden[i], 0.f);
+        ah[(hh * s + r) * s + c] = w;
+        ah[(hh * s + c) * s + r] = w;
+    }
+    // ---- X0 of the graph's nodes
+    float4 *x0s = reinterpret_cast<float4 *>(xs);
+    for (int local = tid; local < ng; local += kBlock) {
+        const size_t node = (size_t)(p0 + local);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.fc_w != nullptr) {
+            // weights from LDS (one broadcast read per term); the sum runs over the input features in order, as in
+            // the stand-alone projection kernel
+            const float *frow = a.feat + node * a.f;
+            float acc[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = c < d ? fcs[d * a.f + c] : 0.f;
+            for (int k = 0; k < a.f; ++k) {
+                const float fv = frow[k];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < d) acc[c] = fmaf(fv, fcs[c * a.f + k], acc[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < d) v[c] = 1.0f / (1.0f + expf(-acc[c]));
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < d) v[c] = 1.0f / (1.0f + expf(-a.feat[node * d + c]));
+        }
+        x0s[local] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+    // ---- the two chains, step by step: Z_i = Ah Z_{i-1} and X_i = A X_{i-1} (rows of the graph, gathered from LDS)
+#pragma unroll
+    for (int i = 1; i < LT; ++i) {
+        const float *zp = zs + (size_t)(i - 1) * h * s * 4;
+        float *zn = zs + (size_t)i * h * s * 4;
+        for (int e = tid; e < h * s * 4; e += kBlock) {
+            const int k = e & 3, r = e >> 2;           // r = hh * s + row
+            const int hh = r / s;
+            const float *arow = ah + (size_t)r * s;
+            float acc = 0.f;
+            for (int c = 0; c < s; ++c) acc = fmaf(arow[c], zp[((hh * s + c) << 2) + k], acc);
+            zn[e] = acc;
+        }
+        const float4 *xp = reinterpret_cast<const float4 *>(xs) + (size_t)(i - 1) * a.max_nodes;
+        float4 *xn = reinterpret_cast<float4 *>(xs) + (size_t)i * a.max_nodes;
+        for (int local = tid, r = 0; local < ng; local += kBlock, ++r) {
+            const int node = p0 + local;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int e0 = r == 0 ? e_beg[0] : r == 1 ? e_beg[1] : a.crow[node];
+            const int e1 = r == 0 ? e_end[0] : r == 1 ? e_end[1] : a.crow[node + 1];
+            // four stored entries per trip, their columns (and values) requested together; entries past the row's end
+            // enter with weight zero (fmaf(0, r, acc) is acc), so the sum runs in stored order whatever the length
+            for (int e = e0; e < e1; e += 4) {
+                int c[4];
+                float w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int at = e + u < e1 ? e + u : e1 - 1;
+                    c[u] = a.col[at] - p0;
+                    w[u] = a.val ? a.val[at] : 1.f;
+                    if (e + u >= e1) w[u] = 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 r = xp[c[u]];
+                    acc.x = fmaf(w[u], r.x, acc.x);
+                    acc.y = fmaf(w[u], r.y, acc.y);
+                    acc.z = fmaf(w[u], r.z, acc.z);
+                    acc.w = fmaf(w[u], r.w, acc.w);
+                }
+            }
+            xn[local] = acc;
+        }
+        __syncthreads();
+    }
+    // ---- Gram matrices of the graph: thread (slot q, row a)
+    {
+        const int q = tid >> 2, ra = tid & 3;
+        const int wave = tid / RWK_WAVE, lane = tid % RWK_WAVE;
+        float acc[LT][4];
+#pragma unroll
+        for (int i = 0; i < LT; ++i)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[i][b] = 0.f;
+        for (int local = q; local < ng; local += kSlots) {
+            const float4 x0 = x0s[local];
+            const float x0a = pick4(x0, ra);
+#pragma unroll
+            for (int i = 0; i < LT; ++i) {
+                const float4 r = i == 0 ? x0 : (reinterpret_cast<const float4 *>(xs) + (size_t)i * a.max_nodes)[local];
+                acc[i][0] = fmaf(x0a, r.x, acc[i][0]);
+                acc[i][1] = fmaf(x0a, r.y, acc[i][1]);
+                acc[i][2] = fmaf(x0a, r.z, acc[i][2]);
+                acc[i][3] = fmaf(x0a, r.w, acc[i][3]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < LT; ++i)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[i][b] = slot_sum16(acc[i][b]);
+        if (lane < 4) {
+#pragma unroll
+            for (int i = 0; i < LT; ++i)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) part[(wave * LT + i) * 16 + ra * 4 + b] = acc[i][b];
+        }
+    }
+    __syncthreads();
+    if (tid < LT * 16) {
+        float v = part[tid];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) v += part[w * LT * 16 + tid];
+        cm[tid] = v;
+    }
+    __syncthreads();
+    // ---- K row of the graph
+    const int lh = LT * h;
+    const float cnt = a.normalize ? a.counts_f32[g] : 1.f;
+    for (int idx = tid; idx < lh; idx += kBlock) {
+        const int i = idx / h, hh = idx - i * h;
+        const float *c = cm + i * 16;
+        const float4 *z0r = reinterpret_cast<const float4 *>(zs) + (size_t)hh * s;
+        const float4 *zir = reinterpret_cast<const float4 *>(zs) + (size_t)(i * h + hh) * s;
+        float sum = 0.f;
+        for (int ss = 0; ss < s; ++ss) {
+            const float4 z0 = z0r[ss], zi = zir[ss];
+            float r = 0.f;
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) {
+                float t = c[aa * 4 + 0] * zi.x;
+                t = fmaf(c[aa * 4 + 1], zi.y, t);
+                t = fmaf(c[aa * 4 + 2], zi.z, t);
+                t = fmaf(c[aa * 4 + 3], zi.w, t);
+                r = fmaf(pick4(z0, aa), t, r);
+            }
+            sum += r;
+        }
+        if (a.normalize) sum /= cnt;
+        if (a.k_out) a.k_out[(size_t)g * lh + idx] = sum;
+        if (a.out) krow[idx] = (sum - bn[idx]) * (1.f / sqrtf(bn[lh + idx] + a.eps)) * bn[2 * lh + idx] + bn[3 * lh + idx];
+    }
+    if (a.out == nullptr) return;
+    __syncthreads();
+    // ---- head on the row: fc1, ReLU, fc2, log-softmax (model.py:68-72 in evaluation mode)
+    // fc1: eight lanes per output, each adding every eighth term, then a fixed xor butterfly over the eight (one lane
+    // walking the whole row waited for an LDS read per term)
+    for (int j0 = 0; j0 < a.p; j0 += kBlock / 8) {
+        const int j = j0 + (tid >> 3), part8 = tid & 7;
+        float acc = 0.f;
+        if (j < a.p) {
+            const float *w = w1s + (size_t)j * lh;
+            for (int c = part8; c < lh; c += 8) acc = fmaf(krow[c], w[c], acc);
+        }
+        acc += __shfl_xor(acc, 1, RWK_WAVE);
+        acc += __shfl_xor(acc, 2, RWK_WAVE);
+        acc += __shfl_xor(acc, 4, RWK_WAVE);
+        if (j < a.p && part8 == 0) h1[j] = fmaxf(acc + b1s[j], 0.f);
+    }
+    __syncthreads();
+    for (int qq = tid; qq < a.nc; qq += kBlock) {
+        float acc = b2s[qq];
+        const float *w = w2s + (size_t)qq * a.p;
+        for (int j = 0; j < a.p; ++j) acc = fmaf(h1[j], w[j], acc);
+        o[qq] = acc;
+    }
+    __syncthreads();
+    for (int qq = tid; qq < a.nc; qq += kBlock) {
+        float mx = o[0];
+        for (int t = 1; t < a.nc; ++t) mx = fmaxf(mx, o[t]);
+        float se = 0.f;
+        for (int t = 0; t < a.nc; ++t) se += expf(o[t] - mx);
+        a.out[(size_t)g * a.nc + qq] = o[qq] - (mx + logf(se));
+    }
+}
+
+inline size_t eval_lds(int64_t h, int64_t s, int64_t l, int64_t max_nodes, int64_t p, int64_t nc) {
+    const int64_t lh = l * h;
+    return (size_t)(l * h * s * 4 + h * s * s + l * max_nodes * 4 + kWaves * l * 16 + l * 16 + lh + p + nc +
+                    (p > 0 ? 4 * lh + p * lh + p + nc * p + nc : 0) + 4 * 16 + 4) *
+           sizeof(float);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t rwk_eval_forward_lds(int64_t d, int64_t h, int64_t s, int64_t max_step, int64_t f, int64_t max_nodes,
+                             int64_t p, int64_t nc) {
+    if (d < 1 || d > 4 || h < 1 || h > 64 || s < 1 || s > 64 || max_step < 1 || max_step > 4) return 0;
+    if (f < 1 || f > 16 || max_nodes < 1 || p < 0 || nc < 0 || p > 4096 || nc > 4096) return 0;
+    const size_t bytes = eval_lds(h, s, max_step, max_nodes, p, nc);
+    return bytes <= kLdsBudget ? (int64_t)bytes : 0;
+}
+
+int rwk_eval_forward(const float *feat, int64_t f, const float *fc_w, const float *fc_b, const float *adj_hidden,
+                     const float *feat_hidden, const int32_t *crow, const int32_t *col, const float *val,
+                     const int32_t *seg_ptr, const float *counts_f32, int64_t n, int64_t n_graphs, int64_t max_nodes,
+                     int64_t d, int64_t h, int64_t s, int64_t max_step, int normalize, const float *bn_w,
+                     const float *bn_b, const float *running_mean, const float *running_var, float eps,
+                     const float *w1, const float *b1, const float *w2, const float *b2, int64_t p, int64_t nc,
+                     float *k_out, float *out, rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(feat);
+    RWK_REQUIRE_PTR(feat_hidden);
+    RWK_REQUIRE_PTR(crow);
+    RWK_REQUIRE_PTR(seg_ptr);
+    if (s > 1) RWK_REQUIRE_PTR(adj_hidden);
+    if (fc_w != nullptr) RWK_REQUIRE_PTR(fc_b);
+    if (normalize) RWK_REQUIRE_PTR(counts_f32);
+    if (k_out == nullptr && out == nullptr) return RWK_E_NULL;
+    if (out != nullptr) {
+        RWK_REQUIRE_PTR(bn_w);
+        RWK_REQUIRE_PTR(bn_b);
+        RWK_REQUIRE_PTR(running_mean);
+        RWK_REQUIRE_PTR(running_var);
+        RWK_REQUIRE_PTR(w1);
+        RWK_REQUIRE_PTR(b1);
+        RWK_REQUIRE_PTR(w2);
+        RWK_REQUIRE_PTR(b2);
+        if (p < 1 || nc < 1) return RWK_E_SIZE;
+    } else {
+        p = 0;
+        nc = 0;
+    }
+    if (n <= 0 || n >= 0x7FFFFFFFll || n_graphs <= 0 || n_graphs > n || max_nodes <= 0) return RWK_E_SIZE;
+    const int64_t f_eff = fc_w != nullptr ? f : 1;
+    const int64_t bytes = rwk_eval_forward_lds(d, h, s, max_step, f_eff, max_nodes, p, nc);
+    if (bytes == 0) return RWK_E_UNSUPPORTED;
+    EvalArgs a{feat, (int)f, fc_w, fc_b, adj_hidden, feat_hidden, crow, col, val, seg_ptr, counts_f32, (int)n, (int)d,
+               (int)h, (int)s, normalize, (int)max_nodes, bn_w, bn_b, running_mean, running_var, eps, w1, b1, w2, b2,
+               (int)p, (int)nc, k_out, out};
+    const dim3 grid((unsigned)n_graphs);
+#define RWK_EVAL(LT)                                                                                          \
+    do {                                                                                                      \
+        if (bytes > 64 * 1024) {                                                                              \
+            hipError_t e = hipFuncSetAttribute((const void *)eval_forward_kernel<LT>,                         \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);      \
+            if (e != hipSuccess) return (int)e;                                                               \
+        }                                                                                                     \
+        hipLaunchKernelGGL(eval_forward_kernel<LT>, grid, dim3(kBlock), (size_t)bytes, (hipStream_t)stream, a); \
+    } while (0)
+    switch (max_step) {
+        case 1: RWK_EVAL(1); break;
+        case 2: RWK_EVAL(2); break;
+        case 3: RWK_EVAL(3); break;
+        default: RWK_EVAL(4); break;
+    }
+#undef RWK_EVAL
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
+}  // extern "C"

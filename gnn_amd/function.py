@@ -38,6 +38,12 @@ FOLD_HEAD_FINISH = True
 # matrix-core path: the forward's dropout keep bits travel to the backward in memory (8 bytes per (node, hidden
 # graph)) instead of being drawn a second time
 KEEP_BITS_HANDOVER = True
+#: without dropout (evaluation mode, dropout 0) and hidden_dim <= 4 the layer runs through per-graph Gram matrices
+#: (csrc/rwk_gram.hip): 16 multiply-adds per node and step instead of 2*H*S*D; False keeps the dropout-shaped kernels
+#: with the identity mask (tests compare the two)
+GRAM_FAST_PATH = True
+#: graphs beyond this many nodes on average stay on the stream kernels (a Gram wavefront walks its graph alone)
+GRAM_MAX_MEAN_NODES = 4096
 
 def choose_stream_len(n_nodes: int, hidden_dim: int, n_hidden: int, size_hidden: int, max_step: int,
                       backward: bool = False) -> int:
@@ -137,6 +143,25 @@ class _RWKernelLayer(torch.autograd.Function):
                            "rwk_hidden_forward")
             for i in range(1, steps):
                 st.spmm(xs[i - 1], xs[i])                                        # model.py:55
+            use_gram = (GRAM_FAST_PATH and drop == 0.0 and n <= GRAM_MAX_MEAN_NODES * g
+                        and bool(lib.rwk_gram_supported(d, n_hidden, s, steps)))
+            if use_gram:                                                         # model.py:45-64 without a mask
+                k = torch.empty((g, steps * n_hidden), dtype=torch.float32, device=dev)
+                gram_c = torch.empty((g, steps, 16), dtype=torch.float32, device=dev) \
+                    if any(ctx.needs_input_grad) else None
+                _lib.check(lib.rwk_gram_forward(xs.data_ptr(), z.data_ptr(), st.seg_ptr.data_ptr(), _lib.ptr(st.perm),
+                                                st.counts_f32.data_ptr(), n, g, d, n_hidden, s, steps,
+                                                int(bool(normalize)), k.data_ptr(), _lib.ptr(gram_c), stream),
+                           "rwk_gram_forward")
+                if handoff is not None:
+                    handoff["fold_ok"] = False
+                ctx.st = st
+                ctx.cfg = (steps, bool(normalize), drop, projected)
+                ctx.fuse_step = fuse_step
+                ctx.handoff = handoff
+                ctx.gram = True
+                ctx.save_for_backward(xs, z, ah, adj_hidden_c, rng_used, inp_c if projected else None, w_c, gram_c)
+                return k
             plan = _plan(lib, st, d, n_hidden, s, steps)
             stream_len = plan["stream_len"]
             k_partials = torch.empty(plan["k_slots"], dtype=torch.float32, device=dev)
@@ -176,6 +201,7 @@ class _RWKernelLayer(torch.autograd.Function):
         ctx.cfg = (steps, bool(normalize), drop, projected)
         ctx.fuse_step = fuse_step
         ctx.handoff = handoff
+        ctx.gram = False
         ctx.save_for_backward(xs, z, ah, adj_hidden_c, rng_used, inp_c if projected else None, w_c, keep)
         return k
 
@@ -195,14 +221,25 @@ class _RWKernelLayer(torch.autograd.Function):
             stream = _lib.current_stream(dev)
             d_k = d_k.contiguous().float()
             dx = torch.empty_like(xs)
-            n_part = plan["n_part"]
-            if n_part <= 0:
-                raise NotImplementedError("unsupported hyper-parameters for the fused backward kernel")
-            dz_partials = torch.empty((n_part, steps * n_hidden * s * d), dtype=torch.float32, device=dev)
-            ws_n = plan["ws"]
-            ws = torch.empty(ws_n, dtype=torch.float32, device=dev) if ws_n else None
             fold = ctx.handoff.pop("head_fold", None) if ctx.handoff is not None else None
-            if fold is not None:
+            if ctx.gram:
+                # Gram path: `keep` is C (G, L, 4, 4); dX from dC = dK M, dZ through dM = sum_g dK C
+                dz_partials = torch.empty((1, steps * n_hidden * s * d), dtype=torch.float32, device=dev)
+                _lib.check(lib.rwk_gram_backward(xs.data_ptr(), z.data_ptr(), st.seg_ptr.data_ptr(), _lib.ptr(st.perm),
+                                                 st.counts_f32.data_ptr(), d_k.data_ptr(), keep.data_ptr(), n,
+                                                 st.n_graphs, d, n_hidden, s, steps, int(normalize), dx.data_ptr(),
+                                                 dz_partials.data_ptr(), stream), "rwk_gram_backward")
+                n_part = 1
+            else:
+                n_part = plan["n_part"]
+                if n_part <= 0:
+                    raise NotImplementedError("unsupported hyper-parameters for the fused backward kernel")
+                dz_partials = torch.empty((n_part, steps * n_hidden * s * d), dtype=torch.float32, device=dev)
+                ws_n = plan["ws"]
+                ws = torch.empty(ws_n, dtype=torch.float32, device=dev) if ws_n else None
+            if ctx.gram:
+                pass
+            elif fold is not None:
                 # the head left its finishing launch out: d_k is a placeholder, the kernel forms it (head.py)
                 _lib.check(lib.rwk_fused_backward_bn(
                     xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm), st.counts_f32.data_ptr(), n, d,

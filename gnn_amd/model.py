@@ -14,6 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.parameter import Parameter
 
+from .eval import eval_forward, eval_forward_supported
 from .function import FUSED_PROJECTION_MAX_INPUT_DIM, rw_kernel_layer, rw_kernel_layer_projected
 from .head import fused_head, fused_head_loss, head_supported
 from .losses import cross_entropy
@@ -62,6 +63,14 @@ class RW_NN(nn.Module):
 
     def forward(self, adj, features, graph_indicator):
         structure = get_structure(adj, graph_indicator)
+        if not self.training and eval_forward_supported(self, structure, features):
+            # model.eval(): the validation / test call of rwgnn2/main.py:110-117,148-151 as one launch
+            return eval_forward(self, structure, features)
+        return self._forward_launches(structure, features)
+
+    def _forward_launches(self, structure, features):
+        """The forward pass as separate launches (training mode, and every shape the one-launch evaluation forward
+        does not serve)."""
         p = float(self.dropout.p)
         drop = p if self.training else 0.0
         if drop >= 1.0:

@@ -524,6 +524,50 @@ int rwk_reduce_rows(const float *in, int64_t p, int64_t v, float *out, float *wo
  * after it (p itself when p <= 32, else 32); rwk_hidden_backward adds up to 32 rows itself. */
 int64_t rwk_reduce_rows_level1(int64_t p);
 int rwk_reduce_rows_to32(const float *in, int64_t p, int64_t v, float *out32, rwk_stream_t stream);
+/* ---------------------------------------------------------------------------------------
+ * The layer WITHOUT dropout (model.eval(), or dropout 0) through per-graph Gram matrices: rwgnn2/model.py:45-64 with
+ * the identity mask factorises as K[g, i*H+h] = sum_s Z0[h,s]^T C[g,i] Zi[h,s], C[g,i] = sum_{n in g} X0[n] (x)
+ * Xi[n] - d*d multiply-adds per node and step instead of 2*H*S*d.  The reference's validation and test loops
+ * (rwgnn2/main.py:110-117,148-151) run this forward every epoch.  hidden_dim d <= 4, h <= 64, s <= 64, max_step <= 4
+ * (rwk_gram_supported).  x (max_step, n, d), z (max_step, h, s, d), seg_ptr (n_graphs + 1) and perm / counts_f32 as
+ * rwk_fused_forward takes them.
+ *   rwk_gram_forward:  k (n_graphs, max_step*h), column i*h + hh, divided by counts when normalize; c_out (may be
+ *                      NULL) keeps C as (n_graphs, max_step, 4, 4) for the backward.
+ *   rwk_gram_backward: given d_k and C: dx (max_step, n, d) (every row written; dC[g,i] = sum_h d_k[g, i*h+hh]
+ *                      sum_s Z0 (x) Zi) and, in a second launch, dz (max_step, h, s, d) through
+ *                      dM[i,h] = sum_g d_k[g, i*h+hh] C[g,i] (graphs added in a fixed strided order).
+ * Fixed summation orders throughout: bitwise reproducible.
+ * ------------------------------------------------------------------------------------- */
+int rwk_gram_supported(int64_t d, int64_t h, int64_t s, int64_t max_step);
+int rwk_gram_forward(const float *x, const float *z, const int32_t *seg_ptr, const int32_t *perm,
+                     const float *counts_f32, int64_t n, int64_t n_graphs, int64_t d, int64_t h, int64_t s,
+                     int64_t max_step, int normalize, float *k, float *c_out, rwk_stream_t stream);
+int rwk_gram_backward(const float *x, const float *z, const int32_t *seg_ptr, const int32_t *perm,
+                      const float *counts_f32, const float *d_k, const float *c_in, int64_t n, int64_t n_graphs,
+                      int64_t d, int64_t h, int64_t s, int64_t max_step, int normalize, float *dx, float *dz,
+                      rwk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * RW_NN.forward in evaluation mode (rwgnn2/model.py:31-72 under model.eval(): identity dropout, batch-norm on its
+ * running statistics - what the validation and test loops rwgnn2/main.py:110-117,148-151 call) as ONE launch, one
+ * workgroup per graph: projection, propagation on the graph's own CSR rows, hidden-graph chain, Gram matrices, K row
+ * and the head, all in LDS.  Requires a block-diagonal matrix (no stored entry joins two graphs), graph ids sorted,
+ * hidden_dim d <= 4, at most max_nodes nodes per graph, and rwk_eval_forward_lds(...) != 0 (bytes of LDS the launch
+ * takes; 0 = the shape does not fit: use the separate launches).  feat: raw features (n, f), f <= 16, with fc_w (d, f)
+ * and fc_b - or, with fc_w NULL, the pre-activations (n, d).  crow / col / val: the int32 CSR (val NULL: all ones).
+ * out (n_graphs, nc) log-probabilities, or NULL to stop after k_out (n_graphs, max_step*h) (either may be NULL, not
+ * both); the head arguments are read only when out is given.
+ * ------------------------------------------------------------------------------------- */
+int64_t rwk_eval_forward_lds(int64_t d, int64_t h, int64_t s, int64_t max_step, int64_t f, int64_t max_nodes,
+                             int64_t p, int64_t nc);
+int rwk_eval_forward(const float *feat, int64_t f, const float *fc_w, const float *fc_b, const float *adj_hidden,
+                     const float *feat_hidden, const int32_t *crow, const int32_t *col, const float *val,
+                     const int32_t *seg_ptr, const float *counts_f32, int64_t n, int64_t n_graphs, int64_t max_nodes,
+                     int64_t d, int64_t h, int64_t s, int64_t max_step, int normalize, const float *bn_w,
+                     const float *bn_b, const float *running_mean, const float *running_var, float eps,
+                     const float *w1, const float *b1, const float *w2, const float *b2, int64_t p, int64_t nc,
+                     float *k_out, float *out, rwk_stream_t stream);
+
 /* rwk_reduce_rows for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same kernels, same order of
  * additions, same bits as rwk_reduce_rows; the 32 x v level-1 sums live in a device array of the library itself

@@ -17,6 +17,15 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True)
+def stream_kernels_without_dropout(monkeypatch):
+    """This file exercises the launch structure of the training step on the stream kernels (statistics hand-over,
+    folded head finish, optimiser in the last launch) with and without dropout; without dropout the layer would
+    otherwise take the Gram-matrix path, which has its own tests (test_gpu_gram.py)."""
+    import gnn_amd.function as fn
+    monkeypatch.setattr(fn, "GRAM_FAST_PATH", False)
+
+
 @pytest.mark.parametrize("p,v", [(1, 7), (32, 640), (33, 5), (1203, 640), (5000, 70)])
 def test_reduce_rows(p, v, dev):
     from gnn_amd import _lib

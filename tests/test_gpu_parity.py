@@ -69,9 +69,15 @@ def test_structure_bit_exact(name, dev):
     assert np.array_equal(st.csr_t.val.cpu().numpy().view(np.uint32), t_val.view(np.uint32))
 
 
+@pytest.mark.parametrize("gram", [True, False])
 @pytest.mark.parametrize("name", CASES)
-def test_layer_forward_backward(name, dev):
-    """K and the layer's VJP (fed the reference's own dL/dK) against the float64 oracle."""
+def test_layer_forward_backward(name, gram, dev, monkeypatch):
+    """K and the layer's VJP (fed the reference's own dL/dK) against the float64 oracle.  The goldens run without
+    dropout: at hidden_dim <= 4 that is the Gram-matrix path (gram = True) or the stream kernels with the identity
+    mask (gram = False, what every shape ran before the Gram path existed); wider shapes take the stream kernels
+    either way."""
+    import gnn_amd.function as fn
+    monkeypatch.setattr(fn, "GRAM_FAST_PATH", gram)
     c = GoldenCase(name)
     m = _model_for(c, dev)
     adj, feats, gi, _ = c.torch_inputs(dev)
@@ -223,7 +229,10 @@ def test_fused_step_launches_equal_separate_launches(name, dev):
     for key in ("k", "adj_hidden", "features_hidden"):
         if key in runs[0]:
             assert torch.equal(runs[0][key], runs[1][key]), key
-    assert rel_err(runs[0]["features"].cpu().numpy(), runs[1]["features"].cpu().numpy().astype(np.float64)) < 1e-6
+    # per-node gradient behind dX_0 + A^T dX_1, whose two terms partly cancel: the two addition orders differ by a few
+    # units in the last place of the larger term (7.7e-7 and 1.1e-6 of the largest entry were measured on
+    # mutag_b2_norm with the stream and the Gram backward); each order is held to 1e-5 against the oracle elsewhere
+    assert rel_err(runs[0]["features"].cpu().numpy(), runs[1]["features"].cpu().numpy().astype(np.float64)) < 3e-6
     # sums of signed per-node terms: equal up to the rounding of a float32 sum of that many terms
     n_nodes = c.n_nodes
     for key in ("fc.weight", "fc.bias"):

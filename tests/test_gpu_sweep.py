@@ -53,9 +53,15 @@ def batch():
 
 
 @pytest.mark.parametrize("h,s,d,steps,normalize", SWEEP)
-@pytest.mark.parametrize("p", [0.0, 0.3])
-def test_layer_sweep(h, s, d, steps, normalize, p, batch, dev):
+@pytest.mark.parametrize("p", [0.0, 0.3, -1.0])
+def test_layer_sweep(h, s, d, steps, normalize, p, batch, dev, monkeypatch):
     from gnn_amd import _lib, get_structure, rw_kernel_layer
+    import gnn_amd.function as fn
+    if p < 0:                        # no dropout on the stream kernels (identity mask) instead of the Gram path
+        if d > 4:
+            pytest.skip("the Gram path serves hidden_dim <= 4 only: p = 0.0 already ran the stream kernels")
+        monkeypatch.setattr(fn, "GRAM_FAST_PATH", False)
+        p = 0.0
     n, gi, idx, val = batch
     rng = np.random.default_rng(h * 1000 + s * 100 + d * 10 + steps)
     pre = rng.normal(size=(n, d)).astype(np.float32)
