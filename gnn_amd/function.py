@@ -106,8 +106,8 @@ class _RWKernelLayer(torch.autograd.Function):
             raise ValueError(f"input has shape {tuple(inp.shape)} for {n} nodes and hidden_dim {d}")
         if n_hidden > 64 or d > 64 or steps > 4:
             raise NotImplementedError(
-                "the HIP kernels cover hidden_graphs <= 64, hidden_dim <= 64, max_step <= 4 "
-                f"(got {n_hidden}, {d}, {steps})")
+                "one launch covers hidden_graphs <= 64, hidden_dim <= 64, max_step <= 4 "
+                f"(got {n_hidden}, {d}, {steps}): call rw_kernel_layer, which composes larger shapes")
         drop = float(drop_p) if (drop_p and rng_state is not None) else 0.0
         with _lib.device_guard(dev):
             stream = _lib.current_stream(dev)
@@ -341,6 +341,17 @@ class _RWKernelLayer(torch.autograd.Function):
         return d_inp, d_w, d_b, (d_adj if steps > 1 else None), d_feat, None, None, None, None, None, None
 
 
+def _composed(pre, adj_hidden, features_hidden, structure, max_step, normalize, drop_p, rng_state):
+    from .wide import rw_kernel_layer_composed
+    return rw_kernel_layer_composed(pre, adj_hidden, features_hidden, structure, max_step, normalize, drop_p, rng_state)
+
+
+def _beyond_direct_range(features_hidden, max_step) -> bool:
+    """Hyper-parameters the fused kernels do not take in one launch (the reference accepts any, main.py:22-27)."""
+    n_hidden, _, d = features_hidden.shape
+    return n_hidden > 64 or d > 64 or int(max_step) > 4
+
+
 def rw_kernel_layer(pre, adj_hidden, features_hidden, structure: GraphStructure, max_step: int,
                     normalize: bool, drop_p: float = 0.0, rng_state=None, handoff=None):
     """(G, max_step*H) random-walk-kernel features; ``pre`` is ``fc(features)`` BEFORE the sigmoid.
@@ -348,6 +359,8 @@ def rw_kernel_layer(pre, adj_hidden, features_hidden, structure: GraphStructure,
     ``handoff``: a dict ``{"head_drop": bool}`` from a caller that feeds K to the fused head in training mode: the
     K reduction then also leaves the head's batch-statistics partials (``handoff["stats"]``, ``["n_stats"]``) and
     draws the head's dropout generator state (``["rng_used"]``), which saves the head its statistics launch."""
+    if _beyond_direct_range(features_hidden, max_step):
+        return _composed(pre, adj_hidden, features_hidden, structure, max_step, normalize, drop_p, rng_state)
     return _RWKernelLayer.apply(pre, None, None, adj_hidden, features_hidden, structure, max_step, normalize,
                                 drop_p, rng_state, handoff)
 
@@ -357,5 +370,8 @@ def rw_kernel_layer_projected(features, fc_weight, fc_bias, adj_hidden, features
                               rng_state=None, handoff=None):
     """Same, with the input projection ``sigmoid(features @ fc_weight.T + fc_bias)`` fused in
     (``features.shape[1] <= FUSED_PROJECTION_MAX_INPUT_DIM``)."""
+    if _beyond_direct_range(features_hidden, max_step):
+        pre = torch.nn.functional.linear(features, fc_weight, fc_bias)
+        return _composed(pre, adj_hidden, features_hidden, structure, max_step, normalize, drop_p, rng_state)
     return _RWKernelLayer.apply(features, fc_weight, fc_bias, adj_hidden, features_hidden, structure, max_step,
                                 normalize, drop_p, rng_state, handoff)
