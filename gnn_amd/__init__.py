@@ -9,5 +9,6 @@ layer and the per-hidden-node model of ``rwgnn_pyg.py:19-170`` on the same kerne
 from .model import RW_NN
 from .structure import GraphStructure, clear_structure_cache, get_structure
 from .function import rw_kernel_layer
+from .optim import Adam
 
-__all__ = ["RW_NN", "GraphStructure", "get_structure", "clear_structure_cache", "rw_kernel_layer"]
+__all__ = ["RW_NN", "Adam", "GraphStructure", "get_structure", "clear_structure_cache", "rw_kernel_layer"]

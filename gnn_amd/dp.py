@@ -47,8 +47,11 @@ class FlatGradBucket:
     in place, ``zero()`` clears the buffer with one fill and ``all_reduce()`` issues one collective.
     """
 
-    def __init__(self, module: torch.nn.Module):
-        self.params = [p for p in module.parameters() if p.requires_grad]
+    def __init__(self, module, bind_grads: bool = True):
+        """``module``: an ``nn.Module`` or an iterable of parameters.  ``bind_grads=False`` leaves the parameters'
+        ``.grad`` alone (a caller that gathers them with :meth:`gather` or inside the optimiser's launch)."""
+        params = module.parameters() if isinstance(module, torch.nn.Module) else module
+        self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("module has no trainable parameters")
         dev, dtype = self.params[0].device, self.params[0].dtype
@@ -56,7 +59,7 @@ class FlatGradBucket:
         self.flat = torch.zeros(total, dtype=dtype, device=dev)
         self._avg_ok = None                # whether the backend accepted ReduceOp.AVG (unknown until first use)
         off = 0
-        for p in self.params:
+        for p in self.params if bind_grads else ():
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
             off += n
