@@ -179,14 +179,14 @@ def time_kernels(batch_t, hp, budget_ms=150.0, only=None):
             mean, invstd, bn_w = torch.zeros(c_, device=dev), torch.ones(c_, device=dev), torch.ones(c_, device=dev)
             hpart = torch.randn((lib.rwk_head_n_blocks(g), lib.rwk_head_grad_size(c_, p_, nc_)), device=dev) / g
             o_gamma = nc_ * p_ + nc_ + p_ * c_ + p_
-            one = torch.ones((), device=dev)
+            d_loss_one = torch.ones((), device=dev)
 
             def run_bwd_bn():
                 _lib.check(lib.rwk_fused_backward_bn(
                     xs.data_ptr(), z.data_ptr(), st.gid.data_ptr(), _lib.ptr(st.perm), st.counts_f32.data_ptr(), n, d,
                     h, s, steps, stream_len_b, p, 0, rng.data_ptr(), dx.data_ptr(), dz_part.data_ptr(), kk.data_ptr(),
                     dy.data_ptr(), mean.data_ptr(), invstd.data_ptr(), bn_w.data_ptr(), hpart.data_ptr(),
-                    hpart.shape[0], hpart.shape[1], o_gamma, one.data_ptr(), g, stream), "bwd_bn")
+                    hpart.shape[0], hpart.shape[1], o_gamma, d_loss_one.data_ptr(), g, stream), "bwd_bn")
 
     lh = steps * h
     # algorithmic HBM bytes per launch (fp32 and int32 are 4 bytes):

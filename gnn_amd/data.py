@@ -202,9 +202,11 @@ class DeviceDataset:
             if n == 0:
                 raise ValueError("empty batch")
             # |column - first row of the row's 256-row block| must fit int16 for the compact columns
-            fits16 = int(np.diff(table[0]).max()) + 255 <= 32767
+            max_graph = int(np.diff(table[0]).max())
+            fits16 = max_graph + 255 <= 32767
             yb = self.y_h[ids]
-            metas.append((b, n, nnz, int(self.graph_max_degree_h[ids].max()), fits16, off, int(yb.min()), int(yb.max())))
+            metas.append((b, n, nnz, int(self.graph_max_degree_h[ids].max()), fits16, off, int(yb.min()), int(yb.max()),
+                          max_graph))
             tables.append(table.reshape(-1))
             off += table.size
         flat = np.concatenate(tables) if len(tables) > 1 else tables[0]
@@ -224,7 +226,7 @@ class DeviceDataset:
         from .structure import GraphStructure, register_structure
         lib = _lib.load()
         dev = self.device
-        b, n, nnz, max_degree, fits16, off, y_lo, y_hi = plan.metas[i]
+        b, n, nnz, max_degree, fits16, off, y_lo, y_hi, max_graph = plan.metas[i]
         f = self.n_feat
         with _lib.device_guard(dev):
             if slot is None:
@@ -269,6 +271,7 @@ class DeviceDataset:
                 st = GraphStructure.from_parts(dev, n, nnz, b, crow, col, val, col16, self.unit_values, max_degree,
                                                gid, seg_ptr, counts, counts_f32)
                 st.plan_tables = plan.tables       # the launch reads them asynchronously
+                st.eval_facts = (max_graph, True)  # largest graph; block-diagonal by construction (gnn_amd.eval)
                 register_structure(adj, gi, st)
             # an asymmetric data set needs the transposed CSR as well: get_structure builds it on first use
             return adj, feats, gi, yy

@@ -42,6 +42,10 @@ KEEP_BITS_HANDOVER = True
 #: (csrc/rwk_gram.hip): 16 multiply-adds per node and step instead of 2*H*S*D; False keeps the dropout-shaped kernels
 #: with the identity mask (tests compare the two)
 GRAM_FAST_PATH = True
+#: block-diagonal batches (sorted graph ids, no stored entry between two graphs, graphs that fit the LDS): projection,
+#: every propagation step and the hidden graphs in ONE launch, one workgroup per graph (csrc/rwk_eval.hip), instead of
+#: the projection launch followed by one SpMM launch per step; False keeps those (tests compare the two)
+GRAPH_X_CHAIN = True
 #: graphs beyond this many nodes on average stay on the stream kernels (a Gram wavefront walks its graph alone)
 GRAM_MAX_MEAN_NODES = 4096
 
@@ -124,7 +128,23 @@ class _RWKernelLayer(torch.autograd.Function):
             fuse_step = (projected and d == 4 and steps >= 2 and MERGED_LAUNCHES and FUSED_STEP_LAUNCHES
                          and 4 * f_in + 4 <= 64 and st.nnz > 0
                          and use_tile_kernel(n, st.nnz, st.csr_t.max_degree, 4))
-            if projected and d == 4 and MERGED_LAUNCHES:                       # model.py:39-43,56 in one launch
+            x_chain = False
+            # (rows of more than 64 stored entries are summed in tree order by the tile SpMM: left to it)
+            if (projected and d == 4 and MERGED_LAUNCHES and GRAPH_X_CHAIN and st.perm is None and st.nnz > 0
+                    and st.csr.max_degree <= 64):
+                from .eval import _facts
+                max_nodes, block_diagonal = _facts(st)
+                x_chain = block_diagonal and bool(lib.rwk_x_chain_lds(f_in, max_nodes, s))
+            if x_chain:                                                          # model.py:39-43,55-56 in one launch
+                w_c = fc_weight.detach().contiguous()
+                csr = st.csr
+                _lib.check(lib.rwk_x_chain_hidden_forward(
+                    inp_c.data_ptr(), w_c.data_ptr(), fc_bias.detach().contiguous().data_ptr(), n, f_in,
+                    csr.crow.data_ptr(), _lib.ptr(csr.col), None if csr.unit_values else _lib.ptr(csr.val),
+                    st.seg_ptr.data_ptr(), g, max_nodes, steps, xs.data_ptr(), _lib.ptr(adj_hidden_c),
+                    feat_c.data_ptr(), n_hidden, s, ah.data_ptr(), z.data_ptr(), rng_in, _lib.ptr(rng_used), stream),
+                    "rwk_x_chain_hidden_forward")
+            elif projected and d == 4 and MERGED_LAUNCHES:                     # model.py:39-43,56 in one launch
                 w_c = fc_weight.detach().contiguous()
                 _lib.check(lib.rwk_project_hidden_forward(
                     inp_c.data_ptr(), w_c.data_ptr(), fc_bias.detach().contiguous().data_ptr(), n, inp_c.shape[1], d,
@@ -141,7 +161,7 @@ class _RWKernelLayer(torch.autograd.Function):
                 _lib.check(lib.rwk_hidden_forward(_lib.ptr(adj_hidden_c), feat_c.data_ptr(), n_hidden, s, d, steps,
                                                   ah.data_ptr(), z.data_ptr(), rng_in, _lib.ptr(rng_used), stream),
                            "rwk_hidden_forward")
-            for i in range(1, steps):
+            for i in range(1, 1 if x_chain else steps):
                 st.spmm(xs[i - 1], xs[i])                                        # model.py:55
             use_gram = (GRAM_FAST_PATH and drop == 0.0 and n <= GRAM_MAX_MEAN_NODES * g
                         and bool(lib.rwk_gram_supported(d, n_hidden, s, steps)))

@@ -568,6 +568,19 @@ int rwk_eval_forward(const float *feat, int64_t f, const float *fc_w, const floa
                      const float *w1, const float *b1, const float *w2, const float *b2, int64_t p, int64_t nc,
                      float *k_out, float *out, rwk_stream_t stream);
 
+/* The node features of every step and the hidden graphs in one launch (model.py:39-43,55-56 at hidden_dim 4 with
+ * at most 16 input features), for block-diagonal batches with sorted graph ids: the workgroup of graph g projects
+ * its nodes into LDS and gathers each propagation step from there; xs (max_step, n, 4) receives every X_i; the
+ * first h workgroups do what rwk_hidden_forward does (ah, z, generator state).  Replaces
+ * rwk_project_hidden_forward followed by max_step - 1 SpMM launches; same bits for rows of at most 64 stored
+ * entries.  rwk_x_chain_lds: bytes of LDS the launch takes, 0 when a graph of max_nodes nodes does not fit. */
+int64_t rwk_x_chain_lds(int64_t f, int64_t max_nodes, int64_t s);
+int rwk_x_chain_hidden_forward(const float *features, const float *weight, const float *bias, int64_t n, int64_t f,
+                               const int32_t *crow, const int32_t *col, const float *val, const int32_t *seg_ptr,
+                               int64_t n_graphs, int64_t max_nodes, int64_t max_step, float *xs,
+                               const float *adj_hidden, const float *features_hidden, int64_t h, int64_t s, float *ah,
+                               float *z, uint64_t *rng_state, uint64_t *rng_used, rwk_stream_t stream);
+
 /* rwk_reduce_rows for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same kernels, same order of
  * additions, same bits as rwk_reduce_rows; the 32 x v level-1 sums live in a device array of the library itself

@@ -3,7 +3,7 @@
 cfg=${1:-stream_h64}
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 rm -rf gpurun_out/pc
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pc -- python3 bench.py --config $cfg --mode eager --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/pc.log 2>&1 || { tail -5 gpurun_out/pc.log; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pc -- python3 bench.py --config $cfg --mode eager --steps 30 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/pc.log 2>&1 || { tail -5 gpurun_out/pc.log; exit 1; }
 python3 - <<PY
 import csv, glob, os
 f = max(glob.glob("gpurun_out/pc/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)

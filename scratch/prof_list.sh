@@ -2,7 +2,7 @@
 # usage on the GPU box: bash scratch/prof_list.sh  -> per-kernel average durations of an eager training run
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 rm -rf gpurun_out/ph
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ph -- python3 bench.py --mode eager --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/ph.log 2>&1 || { tail -5 gpurun_out/ph.log; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ph -- python3 bench.py --mode eager --steps 30 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/ph.log 2>&1 || { tail -5 gpurun_out/ph.log; exit 1; }
 python3 - <<PY
 import csv, glob, os
 f = max(glob.glob("gpurun_out/ph/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)

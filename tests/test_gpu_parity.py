@@ -429,3 +429,35 @@ def test_error_behaviour(dev):
         GraphStructure.build(adj, torch.tensor([1, 1, 2, 2], device=dev))
     with pytest.raises(RuntimeError):
         GraphStructure.build(adj.cpu(), torch.tensor([0, 0, 1, 1]))
+
+
+@pytest.mark.parametrize("name", ["mutag_b0", "mutag_b2_norm", "step1", "tiny_graphs_step4", "directed3_dups"])
+@pytest.mark.parametrize("train_drop", [False, True])
+def test_x_chain_launch_equals_separate_launches(name, train_drop, dev, monkeypatch):
+    """Projection, every propagation step and the hidden graphs in one launch (one workgroup per graph, neighbours
+    gathered from LDS; function.GRAPH_X_CHAIN) against the projection launch followed by one SpMM launch per step:
+    K and every gradient bit for bit - without dropout (the goldens' mode) and in training mode with dropout (the
+    generator state advanced by the same launch)."""
+    import gnn_amd.function as fn
+    from gnn_amd.eval import _facts
+    from gnn_amd.structure import get_structure
+    c = GoldenCase(name)
+    adj, feats, gi, _ = c.torch_inputs(dev)
+    assert _facts(get_structure(adj, gi))[1], "the golden batches are block-diagonal"
+    dk = torch.from_numpy(c["dk"]).to(dev)
+    runs = []
+    for chain in (True, False):
+        monkeypatch.setattr(fn, "GRAPH_X_CHAIN", chain)
+        m = _model_for(c, dev, train=train_drop)
+        if train_drop:
+            m.dropout.p = 0.3
+            m.seed_dropout(7)
+        fe = feats.clone().requires_grad_(True)
+        k = m.rw_features(adj, fe, gi)
+        k.backward(dk)
+        out = {n: p.grad for n, p in (("adj_hidden", m.adj_hidden), ("features_hidden", m.features_hidden),
+                                      ("fc.weight", m.fc.weight), ("fc.bias", m.fc.bias)) if p.grad is not None}
+        runs.append(dict(out, k=k.detach(), features=fe.grad, rng=m._rng_state.clone()))
+    assert runs[0].keys() == runs[1].keys()
+    for key in runs[0]:
+        assert torch.equal(runs[0][key], runs[1][key]), key
