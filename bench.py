@@ -116,7 +116,7 @@ def tile_batch(batch_t, k):
     return adj_k, feats.repeat(k, 1), gi_k, y.repeat(k)
 
 
-def time_kernels(batch_t, hp, budget_ms=150.0, only=None):
+def time_kernels(batch_t, hp, budget_ms=150.0, only=None, in_step=False):
     """Average launch duration of each hand-written kernel class, by launching it back to back through the
     C ABI between two events on the launch stream, with its algorithmic HBM bytes and flops."""
     from gnn_amd import _lib, get_structure
@@ -171,7 +171,7 @@ def time_kernels(batch_t, hp, budget_ms=150.0, only=None):
     # of the head's backward pass in its prologue (rwk_fused_backward_bn: it forms dK itself from what the head left).
     # Timed on buffers of the head's shapes; the roofline entry of the default line is taken from this launch.
     run_bwd_bn = None
-    if p > 0 and "penultimate_dim" in hp and lib.rwk_fused_backward_bn_supported(d, h, s, steps):
+    if in_step and p > 0 and "penultimate_dim" in hp and lib.rwk_fused_backward_bn_supported(d, h, s, steps):
         c_, p_, nc_ = steps * h, hp["penultimate_dim"], hp["n_classes"]
         if lib.rwk_head_train_supported(g, c_, p_, nc_):
             kk = torch.randn((g, c_), device=dev)
@@ -610,7 +610,7 @@ def main():
     # time).
     kern = None
     if rank == 0 and not args.no_kernel_timing:
-        kern = time_kernels(batch_t, hp)
+        kern = time_kernels(batch_t, hp, in_step=True)
     if run_steps is not None:
         run_steps(args.warmup)
     else:
