@@ -17,6 +17,8 @@ __all__ = ["eval_forward_supported", "eval_forward"]
 
 #: False keeps the separate launches in evaluation mode (tests compare the two)
 FUSED_EVAL_FORWARD = True
+#: largest graph the one-workgroup-per-graph forward takes
+MAX_GRAPH_NODES = 2048
 
 
 def _facts(st):
@@ -49,7 +51,9 @@ def eval_forward_supported(model, st, features) -> bool:
             and model.fc2.bias is not None and bn.num_features == model.hidden_graphs * model.max_step):
         return False
     max_nodes, block_diagonal = _facts(st)
-    if not block_diagonal:
+    # one workgroup walks its graph alone: graphs of thousands of nodes, or rows of hundreds of entries (one thread
+    # per row), are better served by the launches that spread a graph over the chip
+    if not block_diagonal or max_nodes > MAX_GRAPH_NODES or st.csr.max_degree > 64:
         return False
     f = features.shape[1] if features.shape[1] <= 16 else 1
     return bool(_lib.load().rwk_eval_forward_lds(d, model.hidden_graphs, model.size_hidden_graphs, model.max_step, f,

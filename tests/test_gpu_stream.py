@@ -83,6 +83,27 @@ def whole_slices(whole, ids):
             np.concatenate(gi), whole.y[np.asarray(ids)])
 
 
+def test_batches_without_edges_and_single_node_graphs():
+    """A data set whose graphs have no edge at all (and one node each): the batch, its structure and a training step."""
+    dev = _dev()
+    import torch.nn.functional as F
+    from gnn_amd import RW_NN
+    from gnn_amd.data import DeviceDataset
+    from gnn_amd.structure import GraphStructure, get_structure
+    ds = DeviceDataset.from_arrays(np.arange(6), np.zeros(6, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32),
+                                   np.ones((5, 1), np.float32), [0, 1, 0, 1, 1], dev)
+    adj, feats, gi, y = ds.batch([4, 0, 2])
+    assert adj.shape == (3, 3) and adj._values().numel() == 0 and gi.cpu().tolist() == [0, 1, 2]
+    assert y.cpu().tolist() == [1, 0, 0]
+    _assert_same_structure(get_structure(adj, gi), GraphStructure.build(adj, gi))
+    torch.manual_seed(0)
+    m = RW_NN(1, 2, 4, 3, 4, 8, False, 2, 0.0, dev).to(dev).train()
+    F.cross_entropy(m(adj, feats, gi), y).backward()
+    assert all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+    m.eval()
+    assert bool(torch.isfinite(m(adj, feats, gi)).all())
+
+
 def test_generic_build_reads_the_device_once(monkeypatch):
     """A batch of foreign tensors (row-major sorted COO, sorted ids: what generate_batches produces) costs one
     device-to-host read."""
