@@ -126,6 +126,9 @@ SIGNATURES = {
     "rwk_adam_step_chunks": (c_int, [_P, _P, _P, _I64, _P, _P, _P, _I64, _P, c_float, c_float, c_float, c_float, _P,
                                      _P]),
     "rwk_dropout_mask": (c_int, [_P, _I64, _I64, _I64, _I64, c_float, _P, _P]),
+    "rwk_model_plan": (c_int, [_P, _P]),
+    "rwk_model_forward": (c_int, [_P, _P, _P, _P, _P]),
+    "rwk_model_backward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -1,0 +1,205 @@
+// One host call per direction for the training-mode model: the launches of model.py:32-72 and of their autograd
+// backward, sequenced here instead of in the caller's language, with every intermediate carved from two
+// caller-owned workspaces.  Host code only: the kernels are those behind the entry points called below, in the
+// order the separate calls make them, so the results are theirs bit for bit.
+#include "rwk_common.h"
+
+namespace {
+
+constexpr int64_t kAlign = 256;
+
+inline int64_t aligned(int64_t bytes) { return (bytes + kAlign - 1) / kAlign * kAlign; }
+
+// forward workspace slots
+enum { F_XS, F_Z, F_AH, F_RNG_LAYER, F_KPART, F_K, F_STATS, F_RNG_HEAD, F_MEAN, F_INVSTD, F_H1D, F_COUNT };
+// backward workspace slots
+enum { B_DX, B_DZ_PART, B_WS, B_DZ32, B_SPB, B_DY, B_HEAD_PART, B_DK, B_COUNT };
+static_assert(F_COUNT <= 12 && B_COUNT <= 8, "rwk_model_plan_t holds 12 forward and 8 backward offsets");
+
+// the rule of the tile SpMM schedule at hidden_dim 4: sparse rows or hubs
+inline bool tile_spmm_serves(int64_t n, int64_t nnz, int32_t max_degree) {
+    const double mean = (double)nnz / (double)(n > 0 ? n : 1);
+    if (mean >= 32.0) return false;
+    return max_degree > 128 || mean * 256.0 >= 48.0;
+}
+
+inline int64_t pairs(int64_t s) { return s * (s - 1) / 2; }
+
+template <class T>
+inline T *at(void *ws, int64_t off) { return reinterpret_cast<T *>(static_cast<char *>(ws) + off); }
+template <class T>
+inline const T *at(const void *ws, int64_t off) { return reinterpret_cast<const T *>(static_cast<const char *>(ws) + off); }
+
+}  // namespace
+
+extern "C" int rwk_model_plan(const rwk_model_step_t *m, rwk_model_plan_t *plan) {
+    if (!m || !plan) return RWK_E_NULL;
+    if (m->n <= 0 || m->n_graphs < 2 || m->f <= 0 || m->nnz <= 0 || m->max_graph_nodes <= 0) return RWK_E_SIZE;
+    const int64_t c = m->h * m->max_step;
+    if (m->d != 4 || m->max_step < 2 || m->max_step > 4 || m->f > 15 || m->h < 1 || m->h > 64 || m->s < 1 ||
+        c > 256 || m->max_degree > 64 || !(m->drop_p >= 0.f) || !(m->drop_p < 1.f))
+        return RWK_E_UNSUPPORTED;
+    if (rwk_x_chain_lds(m->f, m->max_graph_nodes, m->s) <= 0) return RWK_E_UNSUPPORTED;
+    if (!tile_spmm_serves(m->n, m->nnz, m->max_degree_t)) return RWK_E_UNSUPPORTED;
+    if (!rwk_head_supported(m->n_graphs, c, m->p, m->nc)) return RWK_E_UNSUPPORTED;
+    if (rwk_fused_keep_words(m->n, m->d, m->h, m->s, m->max_step) != 0) return RWK_E_UNSUPPORTED;
+
+    rwk_model_plan_t pl = {};
+    pl.stream_len_f = rwk_fused_stream_len(m->n, m->d, m->h, m->s, m->max_step, 0);
+    pl.stream_len_b = rwk_fused_stream_len(m->n, m->d, m->h, m->s, m->max_step, 1);
+    pl.n_partials = rwk_fused_dz_partials_count(m->n, pl.stream_len_b, m->d, m->h, m->s, m->max_step);
+    if (pl.stream_len_f <= 0 || pl.stream_len_b <= 0 || pl.n_partials <= 0) return RWK_E_UNSUPPORTED;
+    pl.dz_rows = pl.n_partials > 32 ? rwk_reduce_rows_level1(pl.n_partials) : pl.n_partials;
+    pl.stats_blocks = rwk_fused_reduce_stats_blocks(m->n_graphs, c);
+    pl.spb_blocks = rwk_spmm_project_backward_blocks(m->n);
+    pl.head_blocks = rwk_head_n_blocks(m->n_graphs);
+    pl.head_grad_floats = rwk_head_grad_size(c, m->p, m->nc);
+    const int64_t k_slots = rwk_fused_k_partials_size(m->n, pl.stream_len_f, m->n_graphs, m->h, m->max_step);
+    const int64_t ws_floats = rwk_fused_backward_workspace(m->n, m->d, m->h, m->s, m->max_step);
+    const int64_t zv = m->max_step * m->h * m->s * m->d;                 // elements of Z (and of one dZ partial)
+    const int64_t wb = m->d * m->f + m->d;
+
+    const int64_t fsz[F_COUNT] = {
+        4 * m->max_step * m->n * m->d,                                   // xs
+        4 * zv,                                                          // z
+        4 * m->h * m->s * m->s,                                          // ah
+        16,                                                              // the layer's drawn generator state
+        4 * k_slots,                                                     // K slot partials
+        4 * m->n_graphs * c,                                             // K
+        4 * rwk_head_stats_size(m->n_graphs, c),                         // batch-statistics partials
+        16,                                                              // the head's drawn generator state
+        4 * c, 4 * c,                                                    // batch mean, 1 / std
+        4 * m->n_graphs * m->p,                                          // fc1 output after ReLU and dropout
+    };
+    int64_t off = 0;
+    for (int i = 0; i < F_COUNT; ++i) { pl.off_f[i] = off; off += aligned(fsz[i]); }
+    pl.forward_bytes = off;
+    const int64_t bsz[B_COUNT] = {
+        4 * m->max_step * m->n * m->d,                                   // dX
+        4 * pl.n_partials * zv,                                          // dZ partials
+        4 * ws_floats,                                                   // the fused backward's own workspace
+        pl.n_partials > 32 ? 4 * pl.dz_rows * zv : 0,                    // dZ partials after the first level
+        4 * pl.spb_blocks * wb,                                          // [dW | db] partial rows
+        4 * m->n_graphs * c,                                             // dY (batch-norm output gradient)
+        4 * pl.head_blocks * pl.head_grad_floats,                        // the head's gradient partial rows
+        4 * m->n_graphs * c,                                             // dK
+    };
+    off = 0;
+    for (int i = 0; i < B_COUNT; ++i) { pl.off_b[i] = off; off += aligned(bsz[i]); }
+    pl.backward_bytes = off;
+    pl.grad_floats = m->h * pairs(m->s) + m->h * m->s * m->d + wb + pl.head_grad_floats;
+    *plan = pl;
+    return RWK_OK;
+}
+
+static int check_step(const rwk_model_step_t *m, const rwk_model_plan_t *plan) {
+    if (!m || !plan) return RWK_E_NULL;
+    if (!m->features || !m->crow || !m->col || !m->crow_t || !m->col_t || !m->seg_ptr || !m->gid || !m->counts_f32 ||
+        !m->fc_w || !m->fc_b || !m->features_hidden || !m->bn_w || !m->bn_b || !m->w1 || !m->b1 || !m->w2 || !m->b2 ||
+        !m->running_mean || !m->running_var)
+        return RWK_E_NULL;
+    if (m->s > 1 && !m->adj_hidden) return RWK_E_NULL;
+    if (m->drop_p > 0.f && !m->rng_state) return RWK_E_NULL;
+    if (!m->val_t && !(m->col16_t && m->unit_values_t)) return RWK_E_NULL;
+    if (plan->forward_bytes <= 0 || plan->backward_bytes <= 0) return RWK_E_SIZE;
+    return RWK_OK;
+}
+
+extern "C" int rwk_model_forward(const rwk_model_step_t *m, const rwk_model_plan_t *plan, void *forward_ws, float *out,
+                                 rwk_stream_t stream) {
+    int rc = check_step(m, plan);
+    if (rc) return rc;
+    if (!forward_ws || !out) return RWK_E_NULL;
+    if (reinterpret_cast<uintptr_t>(forward_ws) % kAlign) return RWK_E_ALIGN;
+    const int64_t *o = plan->off_f;
+    const bool drop = m->drop_p > 0.f;
+    const int64_t c = m->h * m->max_step;
+    float *xs = at<float>(forward_ws, o[F_XS]), *z = at<float>(forward_ws, o[F_Z]);
+    float *k = at<float>(forward_ws, o[F_K]), *stats = at<float>(forward_ws, o[F_STATS]);
+    uint64_t *rng_layer = drop ? at<uint64_t>(forward_ws, o[F_RNG_LAYER]) : nullptr;
+    uint64_t *rng_head = drop ? at<uint64_t>(forward_ws, o[F_RNG_HEAD]) : nullptr;
+    // model.py:39-43,55-56: X_0 .. X_{L-1}, the hidden graphs, the layer's draw of the generator state
+    rc = rwk_x_chain_hidden_forward(m->features, m->fc_w, m->fc_b, m->n, m->f, m->crow, m->col, m->val, m->seg_ptr,
+                                    m->n_graphs, m->max_graph_nodes, m->max_step, xs, m->adj_hidden, m->features_hidden,
+                                    m->h, m->s, at<float>(forward_ws, o[F_AH]), z, drop ? m->rng_state : nullptr,
+                                    rng_layer, stream);
+    if (rc) return rc;
+    // model.py:45-64: contraction, mask, product, per-stream sums
+    rc = rwk_fused_forward_bits(xs, z, m->gid, nullptr, m->n, m->d, m->h, m->s, m->max_step, plan->stream_len_f,
+                                m->drop_p, rng_layer, at<float>(forward_ws, o[F_KPART]), nullptr, stream);
+    if (rc) return rc;
+    // model.py:60-67: K, the head's batch statistics and its draw of the generator state
+    rc = rwk_fused_reduce_stats(at<float>(forward_ws, o[F_KPART]), m->seg_ptr, m->counts_f32, m->n_graphs, m->h,
+                                m->max_step, plan->stream_len_f, m->drop_p, m->normalize, k, stats,
+                                drop ? m->rng_state : nullptr, rng_head, stream);
+    if (rc) return rc;
+    // model.py:68-72
+    return rwk_head_apply_loss(k, m->n_graphs, c, m->p, m->nc, m->bn_w, m->bn_b, m->running_mean, m->running_var,
+                               m->num_batches_tracked, m->momentum, m->eps, stats, plan->stats_blocks, m->w1, m->b1,
+                               m->w2, m->b2, m->drop_p, rng_head, at<float>(forward_ws, o[F_MEAN]),
+                               at<float>(forward_ws, o[F_INVSTD]), at<float>(forward_ws, o[F_H1D]), out, nullptr, nullptr,
+                               stream);
+}
+
+extern "C" int rwk_model_backward(const rwk_model_step_t *m, const rwk_model_plan_t *plan, const void *forward_ws,
+                                  void *backward_ws, const float *out, const float *d_out, float *grads,
+                                  rwk_stream_t stream) {
+    int rc = check_step(m, plan);
+    if (rc) return rc;
+    if (!forward_ws || !backward_ws || !out || !d_out || !grads) return RWK_E_NULL;
+    if (reinterpret_cast<uintptr_t>(forward_ws) % kAlign || reinterpret_cast<uintptr_t>(backward_ws) % kAlign)
+        return RWK_E_ALIGN;
+    const int64_t *of = plan->off_f, *ob = plan->off_b;
+    const bool drop = m->drop_p > 0.f;
+    const int64_t c = m->h * m->max_step, nd = m->n * m->d;
+    const int64_t zv = m->max_step * m->h * m->s * m->d, wb_n = m->d * m->f + m->d;
+    const float *xs = at<float>(forward_ws, of[F_XS]), *z = at<float>(forward_ws, of[F_Z]);
+    const float *ah = at<float>(forward_ws, of[F_AH]), *k = at<float>(forward_ws, of[F_K]);
+    const uint64_t *rng_layer = drop ? at<uint64_t>(forward_ws, of[F_RNG_LAYER]) : nullptr;
+    float *dx = at<float>(backward_ws, ob[B_DX]), *dz_part = at<float>(backward_ws, ob[B_DZ_PART]);
+    float *d_k = at<float>(backward_ws, ob[B_DK]), *spb = at<float>(backward_ws, ob[B_SPB]);
+    float *d_adj = m->s > 1 ? grads : nullptr;
+    float *d_feat = grads + m->h * pairs(m->s);
+    float *wb = d_feat + m->h * m->s * m->d;
+    float *head_grads = wb + wb_n;
+    // the head (model.py:68-72)
+    rc = rwk_head_backward(k, m->n_graphs, c, m->p, m->nc, m->bn_w, m->bn_b, at<float>(forward_ws, of[F_MEAN]),
+                           at<float>(forward_ws, of[F_INVSTD]), 1, m->w1, m->w2, at<float>(forward_ws, of[F_H1D]), out,
+                           d_out, m->drop_p, at<float>(backward_ws, ob[B_DY]), at<float>(backward_ws, ob[B_HEAD_PART]),
+                           head_grads, d_k, stream);
+    if (rc) return rc;
+    // model.py:45-64
+    const int64_t ws_floats = rwk_fused_backward_workspace(m->n, m->d, m->h, m->s, m->max_step);
+    rc = rwk_fused_backward_bits(xs, z, m->gid, nullptr, d_k, m->counts_f32, m->n, m->d, m->h, m->s, m->max_step,
+                                 plan->stream_len_b, m->drop_p, m->normalize, rng_layer, dx, dz_part,
+                                 ws_floats ? at<float>(backward_ws, ob[B_WS]) : nullptr, nullptr, stream);
+    if (rc) return rc;
+    // first level of the dZ partial sum: independent of the propagation chain, it rides in its first launch
+    bool job = plan->n_partials > 32;
+    const float *dz = job ? at<float>(backward_ws, ob[B_DZ32]) : dz_part;
+    float *dz32 = job ? at<float>(backward_ws, ob[B_DZ32]) : nullptr;
+    const bool compact = m->col16_t != nullptr;
+    const float *val_tile = (compact && m->unit_values_t) ? nullptr : m->val_t;
+    for (int64_t i = m->max_step - 1; i > 1; --i) {                      // dX[i-1] += A^T dX[i] (model.py:55)
+        if (job) {
+            rc = rwk_spmm_tile_reduce_rows(m->crow_t, m->col_t, m->col16_t, val_tile, m->n, m->d, dx + i * nd,
+                                           dx + (i - 1) * nd, 1, dz_part, plan->n_partials, zv, dz32, stream);
+            job = false;
+        } else if (compact) {
+            rc = rwk_spmm_csr_compact(m->crow_t, m->col16_t, m->unit_values_t ? nullptr : m->val_t, m->n, m->d,
+                                      dx + i * nd, dx + (i - 1) * nd, 1, stream);
+        } else {
+            rc = rwk_spmm_csr(m->crow_t, m->col_t, m->val_t, m->n, m->d, dx + i * nd, dx + (i - 1) * nd, 1, 0, nullptr,
+                              0, m->long_threshold_t, stream);
+        }
+        if (rc) return rc;
+    }
+    // the last transposed step, the projection's backward (model.py:43) and, when still due, the dZ level
+    rc = rwk_spmm_project_backward(dx, dx + nd, xs, m->features, m->fc_w, m->n, m->f, m->crow_t, m->col_t, m->col16_t,
+                                   val_tile, spb, nullptr, job ? dz_part : nullptr, job ? plan->n_partials : 0,
+                                   job ? zv : 0, job ? dz32 : nullptr, stream);
+    if (rc) return rc;
+    // hidden graphs (model.py:34-37,56) and the [dW | db] sum
+    return rwk_hidden_backward_reduce(m->adj_hidden, ah, z, dz, plan->dz_rows, m->h, m->s, m->d, m->max_step, d_adj,
+                                      d_feat, spb, plan->spb_blocks, wb_n, wb, stream);
+}

@@ -14,6 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.parameter import Parameter
 
+from .composite import model_step, model_step_supported
 from .eval import eval_forward, eval_forward_supported
 from .function import FUSED_PROJECTION_MAX_INPUT_DIM, rw_kernel_layer, rw_kernel_layer_projected
 from .head import fused_head, fused_head_loss, head_supported
@@ -71,7 +72,7 @@ class RW_NN(nn.Module):
     def _forward_launches(self, structure, features):
         """The forward pass as separate launches (training mode, and every shape the one-launch evaluation forward
         does not serve)."""
-        p = float(self.dropout.p)
+        p = float(self._modules["dropout"].p)
         drop = p if self.training else 0.0
         if drop >= 1.0:
             # every product is dropped (model.py:58 with p = 1): K is exactly zero
@@ -81,6 +82,12 @@ class RW_NN(nn.Module):
             handoff = None
         else:
             handoff = self._head_handoff(structure, drop)
+            if handoff is not None and "tail" not in handoff:
+                entry = model_step_supported(self, structure, features, drop)
+                if entry is not None:                  # the eager loop's step: one autograd node, one call each way
+                    if drop > 0.0 and not self._rng_seeded:
+                        self._seed_from_torch()
+                    return model_step(self, structure, features, entry)
             k = self._rw(features, structure, drop, handoff)
         return self._head(k, drop, handoff)
 
@@ -132,11 +139,12 @@ class RW_NN(nn.Module):
         return k.is_cuda and self._head_fusable(k.shape[0], k.shape[1], drop)
 
     def _head_fusable(self, n_graphs, n_features, drop):
-        bn = self.bn
+        mods = self._modules                   # plain dict reads (nn.Module.__getattr__ costs ~0.3 us each)
+        bn, fc1, fc2 = mods["bn"], mods["fc1"], mods["fc2"]
         return (self.fused_head and drop < 1.0 and bn.affine and bn.track_running_stats
-                and bn.momentum is not None and self.fc1.bias is not None and self.fc2.bias is not None
-                and n_features == bn.num_features
-                and head_supported(n_graphs, n_features, self.fc1.out_features, self.fc2.out_features))
+                and bn.momentum is not None and fc1._parameters["bias"] is not None
+                and fc2._parameters["bias"] is not None and n_features == bn.num_features
+                and head_supported(n_graphs, n_features, fc1.out_features, fc2.out_features))
 
     def _seed_from_torch(self):
         self.seed_dropout(int(torch.randint(0, 2 ** 62, (1,)).item()))

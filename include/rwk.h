@@ -621,6 +621,69 @@ int rwk_adam_step_chunks(float *param, const float *const *srcs, const int64_t *
                          float beta1, float beta2, float eps, float weight_decay, int64_t *step_counters,
                          rwk_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * One call per direction for the whole training-mode model (model.py:32-72 and its autograd backward): the same
+ * launches as the entry points above, in the same order, with every intermediate in two caller-owned workspaces.
+ * An eager training loop (rwgnn2/main.py:82-88) then pays two host calls and three allocations per step instead
+ * of a dozen calls and some thirty allocations.  Forward = rwk_x_chain_hidden_forward, rwk_fused_forward_bits,
+ * rwk_fused_reduce_stats, rwk_head_apply_loss; backward = rwk_head_backward, rwk_fused_backward_bits, the
+ * transposed propagation steps (the first of them with the level-1 sum of the hidden-feature partials in its
+ * launch), rwk_spmm_project_backward, rwk_hidden_backward_reduce.  Results are those of the separate calls, bit
+ * for bit.
+ *
+ * Served shape (rwk_model_plan returns RWK_E_UNSUPPORTED otherwise): hidden_dim 4, 2 <= max_step <= 4, at most 15
+ * input features, a block-diagonal batch with sorted graph ids whose graphs fit rwk_x_chain_lds, rows of at most
+ * 64 stored entries, a transposed matrix the tile SpMM kernel serves, a head rwk_head_supported serves,
+ * h * max_step <= 256.
+ *
+ * rwk_model_step_t (HOST struct) names the batch, the parameters and the hyper-parameters; the library reads it
+ * during the call only.  val / val_t may be NULL when every stored value is 1.0 and (for val_t) col16_t is given.
+ * rng_state ({seed, offset}, advanced by the forward call) may be NULL when drop_p == 0.
+ * rwk_model_plan fills rwk_model_plan_t (HOST struct) for one (batch structure, hyper-parameters) pair: workspace
+ * sizes in bytes and the launch constants; keep it and pass it to both calls.
+ * forward_ws (plan->forward_bytes, 256-byte aligned) is written by rwk_model_forward and read by
+ * rwk_model_backward; backward_ws (plan->backward_bytes) is scratch of the backward call.  out: (n_graphs, nc)
+ * log-probabilities.  grads (plan->grad_floats floats) receives
+ * [d adj_hidden | d features_hidden | d fc.weight (4, f) | d fc.bias (4) | the head's gradient vector in the
+ * layout of rwk_head_backward].
+ * ------------------------------------------------------------------------------------- */
+typedef struct rwk_model_step_t {
+    /* batch */
+    int64_t n, f, nnz, n_graphs, max_graph_nodes;
+    int32_t max_degree, max_degree_t;                        /* longest row of A and of A^T */
+    const float *features;                                   /* (n, f) */
+    const int32_t *crow, *col;                               /* A, CSR */
+    const float *val;
+    const int32_t *crow_t, *col_t;                           /* A^T, CSR (the same arrays when A is symmetric) */
+    const int16_t *col16_t;                                  /* compact columns of A^T or NULL */
+    const float *val_t;
+    int32_t unit_values_t, long_threshold_t;
+    const int32_t *seg_ptr, *gid;
+    const float *counts_f32;
+    /* hyper-parameters */
+    int64_t h, s, d, max_step, p, nc;
+    int32_t normalize, reserved;
+    float drop_p, momentum, eps, reserved_f;
+    /* parameters and state */
+    const float *fc_w, *fc_b, *adj_hidden, *features_hidden, *bn_w, *bn_b, *w1, *b1, *w2, *b2;
+    float *running_mean, *running_var;
+    int64_t *num_batches_tracked;
+    uint64_t *rng_state;
+} rwk_model_step_t;
+
+typedef struct rwk_model_plan_t {
+    int64_t forward_bytes, backward_bytes, grad_floats;
+    int64_t stream_len_f, stream_len_b, n_partials, dz_rows, stats_blocks, spb_blocks, head_blocks, head_grad_floats;
+    int64_t off_f[12];                                       /* byte offsets into forward_ws */
+    int64_t off_b[8];                                        /* byte offsets into backward_ws */
+} rwk_model_plan_t;
+
+int rwk_model_plan(const rwk_model_step_t *m, rwk_model_plan_t *plan);
+int rwk_model_forward(const rwk_model_step_t *m, const rwk_model_plan_t *plan, void *forward_ws, float *out,
+                      rwk_stream_t stream);
+int rwk_model_backward(const rwk_model_step_t *m, const rwk_model_plan_t *plan, const void *forward_ws,
+                       void *backward_ws, const float *out, const float *d_out, float *grads, rwk_stream_t stream);
+
 /* Test hook: writes the keep-mask exactly as the fused kernels draw it, one byte per element,
  * shape (L, H, S, N), for the {seed, offset} in rng. */
 int rwk_dropout_mask(const uint64_t *rng, int64_t n, int64_t h, int64_t s, int64_t max_step,
