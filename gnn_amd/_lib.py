@@ -129,6 +129,7 @@ SIGNATURES = {
     "rwk_model_plan": (c_int, [_P, _P]),
     "rwk_model_forward": (c_int, [_P, _P, _P, _P, _P]),
     "rwk_model_backward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "rwk_model_train_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

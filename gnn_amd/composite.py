@@ -15,10 +15,13 @@ import torch
 
 from . import _lib
 
-__all__ = ["COMPOSITE_STEP", "model_step_supported", "model_step"]
+__all__ = ["COMPOSITE_STEP", "ONE_CALL_TRAIN_STEP", "model_step_supported", "model_step", "TrainStep"]
 
 #: False keeps the separate autograd nodes of the layer and the head (tests compare the two)
 COMPOSITE_STEP = True
+#: ``Trainer``'s eager step as one library call without autograd (``rwk_model_train_step``); False keeps the autograd
+#: path (tests compare the two)
+ONE_CALL_TRAIN_STEP = True
 
 
 class ModelStep(ctypes.Structure):
@@ -46,7 +49,18 @@ class ModelPlan(ctypes.Structure):
         ("forward_bytes", c_int64), ("backward_bytes", c_int64), ("grad_floats", c_int64),
         ("stream_len_f", c_int64), ("stream_len_b", c_int64), ("n_partials", c_int64), ("dz_rows", c_int64),
         ("stats_blocks", c_int64), ("spb_blocks", c_int64), ("head_blocks", c_int64), ("head_grad_floats", c_int64),
-        ("off_f", c_int64 * 12), ("off_b", c_int64 * 8),
+        ("off_f", c_int64 * 12), ("off_b", c_int64 * 8), ("train_step", c_int64),
+    ]
+
+
+class TrainTail(ctypes.Structure):
+    """``rwk_train_tail_t`` of include/rwk.h."""
+    _fields_ = [
+        ("param", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("grad_out", c_void_p),
+        ("n", c_int64), ("off_adj", c_int64), ("off_feat", c_int64), ("off_red", c_int64), ("rest_off", c_int64),
+        ("n_rest", c_int64), ("rest_columns", c_int64 * 8), ("rest_sizes", c_int64 * 8),
+        ("lr", c_void_p), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("weight_decay", c_float),
+        ("step_counters", c_void_p), ("corr_slot", c_void_p),
     ]
 
 
@@ -169,3 +183,120 @@ def model_step(model, st, features, entry):
     return _RWModelStep.apply(features, own["adj_hidden"], own["features_hidden"], fc["weight"], fc["bias"],
                               bn["weight"], bn["bias"], fc1["weight"], fc1["bias"], fc2["weight"], fc2["bias"],
                               model, st, entry)
+
+
+class TrainStep:
+    """``Trainer``'s single-process step (zero_grad, forward, cross-entropy, backward, Adam; ``rwgnn2/main.py:82-88``)
+    as ONE library call, ``rwk_model_train_step``: no autograd graph, no allocation per step beyond the loss scalar.
+    The launches are those of the autograd path with the optimiser's update in the last one (``optim.StepTail``), so
+    parameters, moments, running statistics and generator state come out the same bits.  What an eager loop gains is
+    host time: batches that change every step (``StreamTrainer``) cannot replay a captured graph, and launching the
+    step through autograd costs the host four times what the device needs to run it."""
+
+    def __init__(self, trainer):
+        self.trainer = trainer
+        self.tail_struct = None
+        self.ws = [None, None, None, None]     # forward workspace, backward workspace, gradient vector, output
+        self.flat_views = None
+
+    def _room(self, k, numel, dtype, dev):
+        t = self.ws[k]
+        if t is None or t.numel() < numel:
+            t = torch.empty(max(numel, 1), dtype=dtype, device=dev)
+            self.ws[k] = t
+        return t
+
+    def supported(self, model, st, feats, y, drop):
+        tr = self.trainer
+        tail = tr.tail
+        from . import function as fn
+        if not (ONE_CALL_TRAIN_STEP and tail is not None and tr.loss_in_head and model.training
+                and fn.FOLD_HEAD_FINISH and fn.MERGED_LAUNCHES and fn.FUSED_STEP_LAUNCHES and fn.GRAPH_X_CHAIN
+                and not (drop == 0.0 and fn.GRAM_FAST_PATH) and drop < 1.0
+                and feats.is_cuda and feats.dtype is torch.float32 and feats.dim() == 2 and feats.is_contiguous()
+                and not feats.requires_grad and y.dtype is torch.int64 and y.dim() == 1 and y.is_contiguous()
+                and y.numel() == st.n_graphs and torch.is_grad_enabled()):
+            return None
+        if not model._head_fusable(st.n_graphs, model.hidden_graphs * model.max_step, drop):
+            return None
+        for p in tr.bucket.params:             # nothing may expect autograd to deliver these gradients
+            if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None) \
+                    or not p.is_contiguous():
+                return None
+        entry = _entry(model, st, int(feats.shape[1]), drop)
+        if entry is None or not entry[1].train_step:
+            return None
+        return entry
+
+    def _tail(self, lib, shape):
+        tail, o = self.trainer.tail, self.trainer.opt
+        t = self.tail_struct
+        if t is None:
+            t = TrainTail()
+            c = self.trainer.model.bn.num_features
+            p, nc = self.trainer.model.fc1.out_features, self.trainer.model.fc2.out_features
+            cols = tail.head_columns(c, p, nc)
+            t.n, t.off_adj, t.off_feat, t.off_red, t.rest_off = tail.n, tail.off_adj, tail.off_feat, tail.off_red, \
+                tail.rest_off
+            t.n_rest = len(cols)
+            for i, (col, size) in enumerate(zip(cols, tail.rest_sizes)):
+                t.rest_columns[i], t.rest_sizes[i] = col, size
+            self.tail_struct = t
+        upd = tail.update
+        t.param = o.flat_param.data_ptr() if upd else None
+        t.exp_avg = o.exp_avg.data_ptr() if upd else None
+        t.exp_avg_sq = o.exp_avg_sq.data_ptr() if upd else None
+        t.grad_out = o.bucket.flat.data_ptr()
+        t.lr = o.lr.data_ptr() if upd else None
+        t.beta1, t.beta2, t.eps, t.weight_decay = o.betas[0], o.betas[1], o.eps, o.weight_decay
+        t.step_counters = tail.counters.data_ptr() if upd else None
+        t.corr_slot = _lib.ptr(tail.corr_slot)
+        tail.before_launch(shape)
+        return t
+
+    def run(self, entry, model, st, feats, y):
+        """Queue the step; returns the loss tensor (complete once the step has run)."""
+        from .head import check_labels
+        lib = _lib.load()
+        tr = self.trainer
+        m, plan, _, _ = entry
+        dev = feats.device
+        check_labels(y, m.nc)
+        if m.drop_p > 0.0 and not model._rng_seeded:
+            model._seed_from_torch()
+        with _lib.device_guard(dev):
+            fws = self._room(0, plan.forward_bytes, torch.uint8, dev)
+            bws = self._room(1, plan.backward_bytes, torch.uint8, dev)
+            grads = self._room(2, plan.grad_floats, torch.float32, dev)
+            out = self._room(3, st.n_graphs * m.nc, torch.float32, dev)
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            mods, own = model._modules, model._parameters
+            fc, bn, fc1, fc2 = (mods[k]._parameters for k in ("fc", "bn", "fc1", "fc2"))
+            m.features = feats.data_ptr()
+            m.adj_hidden, m.features_hidden = own["adj_hidden"].data_ptr(), own["features_hidden"].data_ptr()
+            m.fc_w, m.fc_b = fc["weight"].data_ptr(), fc["bias"].data_ptr()
+            m.bn_w, m.bn_b = bn["weight"].data_ptr(), bn["bias"].data_ptr()
+            m.w1, m.b1 = fc1["weight"].data_ptr(), fc1["bias"].data_ptr()
+            m.w2, m.b2 = fc2["weight"].data_ptr(), fc2["bias"].data_ptr()
+            buf = mods["bn"]._buffers
+            m.running_mean, m.running_var = buf["running_mean"].data_ptr(), buf["running_var"].data_ptr()
+            m.num_batches_tracked = _lib.ptr(buf["num_batches_tracked"])
+            m.rng_state = model._buffers["_rng_state"].data_ptr() if m.drop_p > 0.0 else None
+            fold = plan.train_step == 1
+            t = self._tail(lib, "head" if fold else "plain")
+            _lib.check(lib.rwk_model_train_step(ctypes.byref(m), ctypes.byref(plan), ctypes.byref(t), fws.data_ptr(),
+                                                bws.data_ptr(), y.data_ptr(), tr._one.data_ptr(), out.data_ptr(),
+                                                loss.data_ptr(), grads.data_ptr(), _lib.current_stream(dev)),
+                       "rwk_model_train_step")
+        tr.tail.after_launch(fold)
+        # the parameters' gradients: the flat bucket the last launch filled, as zero_grad / backward would leave them
+        views = self.flat_views
+        if views is None or views[0] is not tr.bucket.flat:
+            flat, off, vs = tr.bucket.flat, 0, []
+            for p in tr.bucket.params:
+                vs.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            views = self.flat_views = (flat, vs)
+        for p, v in zip(tr.bucket.params, views[1]):
+            p.grad = v
+        return loss

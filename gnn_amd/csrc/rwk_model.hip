@@ -88,6 +88,9 @@ extern "C" int rwk_model_plan(const rwk_model_step_t *m, rwk_model_plan_t *plan)
     for (int i = 0; i < B_COUNT; ++i) { pl.off_b[i] = off; off += aligned(bsz[i]); }
     pl.backward_bytes = off;
     pl.grad_floats = m->h * pairs(m->s) + m->h * m->s * m->d + wb + pl.head_grad_floats;
+    // 1: the head's batch-norm backward rides in the fused backward kernel; 2: the head finishes in its own launch
+    pl.train_step = !(m->s > 1 && rwk_head_train_supported(m->n_graphs, c, m->p, m->nc)) ? 0
+                    : rwk_fused_backward_bn_supported(m->d, m->h, m->s, m->max_step) ? 1 : 2;
     *plan = pl;
     return RWK_OK;
 }
@@ -202,4 +205,111 @@ extern "C" int rwk_model_backward(const rwk_model_step_t *m, const rwk_model_pla
     // hidden graphs (model.py:34-37,56) and the [dW | db] sum
     return rwk_hidden_backward_reduce(m->adj_hidden, ah, z, dz, plan->dz_rows, m->h, m->s, m->d, m->max_step, d_adj,
                                       d_feat, spb, plan->spb_blocks, wb_n, wb, stream);
+}
+
+extern "C" int rwk_model_train_step(const rwk_model_step_t *m, const rwk_model_plan_t *plan, const rwk_train_tail_t *tail,
+                                    void *forward_ws, void *backward_ws, const int64_t *labels, const float *d_loss,
+                                    float *out, float *loss, float *grads, rwk_stream_t stream) {
+    int rc = check_step(m, plan);
+    if (rc) return rc;
+    if (!tail || !forward_ws || !backward_ws || !labels || !d_loss || !out || !loss || !grads || !tail->grad_out)
+        return RWK_E_NULL;
+    if (tail->param && (!tail->exp_avg || !tail->exp_avg_sq || !tail->lr || !tail->step_counters)) return RWK_E_NULL;
+    if (reinterpret_cast<uintptr_t>(forward_ws) % kAlign || reinterpret_cast<uintptr_t>(backward_ws) % kAlign)
+        return RWK_E_ALIGN;
+    if (!plan->train_step || tail->n_rest != 6) return RWK_E_UNSUPPORTED;
+    const int64_t *of = plan->off_f, *ob = plan->off_b;
+    const bool drop = m->drop_p > 0.f;
+    const int64_t c = m->h * m->max_step, nd = m->n * m->d;
+    const int64_t zv = m->max_step * m->h * m->s * m->d, wb_n = m->d * m->f + m->d;
+    if (tail->off_red + wb_n != tail->rest_off) return RWK_E_SIZE;
+    float *xs = at<float>(forward_ws, of[F_XS]), *z = at<float>(forward_ws, of[F_Z]);
+    float *ah = at<float>(forward_ws, of[F_AH]), *k = at<float>(forward_ws, of[F_K]);
+    float *stats = at<float>(forward_ws, of[F_STATS]);
+    float *mean = at<float>(forward_ws, of[F_MEAN]), *invstd = at<float>(forward_ws, of[F_INVSTD]);
+    uint64_t *rng_layer = drop ? at<uint64_t>(forward_ws, of[F_RNG_LAYER]) : nullptr;
+    uint64_t *rng_head = drop ? at<uint64_t>(forward_ws, of[F_RNG_HEAD]) : nullptr;
+    float *dx = at<float>(backward_ws, ob[B_DX]), *dz_part = at<float>(backward_ws, ob[B_DZ_PART]);
+    float *spb = at<float>(backward_ws, ob[B_SPB]), *dy = at<float>(backward_ws, ob[B_DY]);
+    float *head_part = at<float>(backward_ws, ob[B_HEAD_PART]);
+    float *loss_part = at<float>(forward_ws, of[F_H1D]);     // (the fc1 output is not kept in this shape: its room)
+    float *d_k = at<float>(backward_ws, ob[B_DK]);
+    const bool fold = plan->train_step == 1;
+    float *d_adj = grads, *d_feat = grads + m->h * pairs(m->s);
+    float *wb = d_feat + m->h * m->s * m->d, *head_grads = wb + wb_n;
+    // forward (model.py:32-72) with the loss sums and the tile part of the head's backward (main.py:85)
+    rc = rwk_x_chain_hidden_forward(m->features, m->fc_w, m->fc_b, m->n, m->f, m->crow, m->col, m->val, m->seg_ptr,
+                                    m->n_graphs, m->max_graph_nodes, m->max_step, xs, m->adj_hidden, m->features_hidden,
+                                    m->h, m->s, ah, z, drop ? m->rng_state : nullptr, rng_layer, stream);
+    if (rc) return rc;
+    rc = rwk_fused_forward_bits(xs, z, m->gid, nullptr, m->n, m->d, m->h, m->s, m->max_step, plan->stream_len_f,
+                                m->drop_p, rng_layer, at<float>(forward_ws, of[F_KPART]), nullptr, stream);
+    if (rc) return rc;
+    rc = rwk_fused_reduce_stats(at<float>(forward_ws, of[F_KPART]), m->seg_ptr, m->counts_f32, m->n_graphs, m->h,
+                                m->max_step, plan->stream_len_f, m->drop_p, m->normalize, k, stats,
+                                drop ? m->rng_state : nullptr, rng_head, stream);
+    if (rc) return rc;
+    rc = rwk_head_train_forward(k, m->n_graphs, c, m->p, m->nc, m->bn_w, m->bn_b, m->running_mean, m->running_var,
+                                m->num_batches_tracked, m->momentum, m->eps, stats, plan->stats_blocks, m->w1, m->b1,
+                                m->w2, m->b2, m->drop_p, nullptr, rng_head, mean, invstd, out, labels, loss_part, dy,
+                                head_part, loss, stream);
+    if (rc) return rc;
+    if (fold) {
+        // backward: the head's batch-norm backward rides in the fused kernel's prologue
+        const int64_t o_gamma = m->nc * m->p + m->nc + m->p * c + m->p;
+        rc = rwk_fused_backward_bn(xs, z, m->gid, nullptr, m->counts_f32, m->n, m->d, m->h, m->s, m->max_step,
+                                   plan->stream_len_b, m->drop_p, m->normalize, rng_layer, dx, dz_part, k, dy, mean,
+                                   invstd, m->bn_w, head_part, plan->head_blocks, plan->head_grad_floats, o_gamma,
+                                   d_loss, m->n_graphs, stream);
+    } else {
+        // the head finishes in its own launch (dK, its parameter gradients, the loss value), then the layer
+        rc = rwk_head_train_backward(k, m->n_graphs, c, m->p, m->nc, m->bn_w, mean, invstd, dy, head_part, d_loss,
+                                     loss_part, loss, head_grads, d_k, stream);
+        if (rc) return rc;
+        const int64_t ws_floats = rwk_fused_backward_workspace(m->n, m->d, m->h, m->s, m->max_step);
+        rc = rwk_fused_backward_bits(xs, z, m->gid, nullptr, d_k, m->counts_f32, m->n, m->d, m->h, m->s, m->max_step,
+                                     plan->stream_len_b, m->drop_p, m->normalize, rng_layer, dx, dz_part,
+                                     ws_floats ? at<float>(backward_ws, ob[B_WS]) : nullptr, nullptr, stream);
+    }
+    if (rc) return rc;
+    bool job = plan->n_partials > 32;
+    const float *dz = job ? at<float>(backward_ws, ob[B_DZ32]) : dz_part;
+    float *dz32 = job ? at<float>(backward_ws, ob[B_DZ32]) : nullptr;
+    const bool compact = m->col16_t != nullptr;
+    const float *val_tile = (compact && m->unit_values_t) ? nullptr : m->val_t;
+    for (int64_t i = m->max_step - 1; i > 1; --i) {
+        if (job) {
+            rc = rwk_spmm_tile_reduce_rows(m->crow_t, m->col_t, m->col16_t, val_tile, m->n, m->d, dx + i * nd,
+                                           dx + (i - 1) * nd, 1, dz_part, plan->n_partials, zv, dz32, stream);
+            job = false;
+        } else if (compact) {
+            rc = rwk_spmm_csr_compact(m->crow_t, m->col16_t, m->unit_values_t ? nullptr : m->val_t, m->n, m->d,
+                                      dx + i * nd, dx + (i - 1) * nd, 1, stream);
+        } else {
+            rc = rwk_spmm_csr(m->crow_t, m->col_t, m->val_t, m->n, m->d, dx + i * nd, dx + (i - 1) * nd, 1, 0, nullptr,
+                              0, m->long_threshold_t, stream);
+        }
+        if (rc) return rc;
+    }
+    rc = rwk_spmm_project_backward(dx, dx + nd, xs, m->features, m->fc_w, m->n, m->f, m->crow_t, m->col_t, m->col16_t,
+                                   val_tile, spb, nullptr, job ? dz_part : nullptr, job ? plan->n_partials : 0,
+                                   job ? zv : 0, job ? dz32 : nullptr, stream);
+    if (rc) return rc;
+    if (!fold) {
+        // hidden graphs, the [dW | db] sum and the update; the head's gradients are in memory already
+        const float *srcs[8];
+        for (int64_t i = 0; i < tail->n_rest; ++i) srcs[i] = head_grads + tail->rest_columns[i];
+        return rwk_hidden_backward_reduce_adam(
+            m->adj_hidden, ah, z, dz, plan->dz_rows, m->h, m->s, m->d, m->max_step, d_adj, d_feat, spb,
+            plan->spb_blocks, wb_n, wb, tail->param, tail->exp_avg, tail->exp_avg_sq, tail->grad_out, tail->n,
+            tail->off_adj, tail->off_feat, tail->off_red, srcs, tail->rest_sizes, tail->n_rest, tail->rest_off, tail->lr,
+            tail->beta1, tail->beta2, tail->eps, tail->weight_decay, tail->step_counters, tail->corr_slot, stream);
+    }
+    // hidden graphs, the [dW | db] sum, the head's parameter-gradient sums, the loss value and the update
+    return rwk_hidden_backward_reduce_adam_head(
+        m->adj_hidden, ah, z, dz, plan->dz_rows, m->h, m->s, m->d, m->max_step, d_adj, d_feat, spb, plan->spb_blocks,
+        wb_n, wb, tail->param, tail->exp_avg, tail->exp_avg_sq, tail->grad_out, tail->n, tail->off_adj, tail->off_feat,
+        tail->off_red, tail->rest_columns, tail->rest_sizes, tail->n_rest, tail->rest_off, tail->lr, tail->beta1,
+        tail->beta2, tail->eps, tail->weight_decay, tail->step_counters, tail->corr_slot, head_part, plan->head_blocks,
+        plan->head_grad_floats, d_loss, head_grads, loss_part, loss, m->n_graphs, stream);
 }

@@ -256,6 +256,25 @@ class StepTail:
             raise ValueError("head gradient buffer does not match the optimiser's parameter sizes")
         return [o_ga, o_be, o_w1, o_b1, o_w2, o_b2]
 
+    def before_launch(self, shape: str):
+        """Bookkeeping in front of a launch of shape ``"head"`` (the head's parameter-gradient sums ride along) or
+        ``"plain"``."""
+        o = self.opt
+        # the handed-over bias corrections are those of one (beta1, beta2) pair: other betas start a fresh slot
+        if self.corr_slot is not None and getattr(self, "_slot_betas", o.betas) != o.betas:
+            self.corr_slot.zero_()
+        self._slot_betas = o.betas
+        # the two launch shapes have different workgroup counts, each workgroup advancing its own counter: when the
+        # shape changes, the counters the previous shape did not touch are brought along first
+        if self.update and self._shape is not None and self._shape != shape:
+            self.sync_counters()
+        self._shape = shape
+
+    def after_launch(self, head_fold: bool):
+        """The launch was queued by someone else (``composite.TrainStep``)."""
+        self.head_folds += int(head_fold)
+        self.done = True
+
     def launch(self, lib, stream, head_srcs, adj_hidden, ah, z, dz, dz_rows, n_hidden, s, d, steps, d_adj, d_feat,
                partials, blocks, red_v, red_out, head_fold=None, n_graphs=0, head_columns=None):
         import ctypes
@@ -264,17 +283,8 @@ class StepTail:
         o = self.opt
         n = len(head_srcs)
         sizes = (ctypes.c_int64 * n)(*self.rest_sizes)
-        # the two launch shapes have different workgroup counts, each workgroup advancing its own counter: when the
-        # shape changes, the counters the previous shape did not touch are brought along first
         upd = (lambda t: t.data_ptr()) if self.update else (lambda t: None)
-        # the handed-over bias corrections are those of one (beta1, beta2) pair: other betas start a fresh slot
-        if self.corr_slot is not None and getattr(self, "_slot_betas", o.betas) != o.betas:
-            self.corr_slot.zero_()
-        self._slot_betas = o.betas
-        shape = "head" if head_fold is not None else "plain"
-        if self.update and self._shape is not None and self._shape != shape:
-            self.sync_counters()
-        self._shape = shape
+        self.before_launch("head" if head_fold is not None else "plain")
         if head_fold is not None:
             # the head's finishing launch was left out: its parameter gradients are summed here from its partial rows
             hp_ = head_fold["partials"]

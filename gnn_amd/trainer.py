@@ -20,6 +20,7 @@ import torch.nn.functional as F
 from .dp import FlatGradBucket
 from .losses import cross_entropy
 from .optim import FlatAdam, StepTail
+from .structure import get_structure
 
 __all__ = ["Trainer", "EpochTrainer", "StreamTrainer", "stale_autograd_graph_is_an_error"]
 
@@ -69,6 +70,8 @@ class Trainer:
         self.adj, self.feats, self.gi, self.y = batch_t
         # forward_fn(): the model's scores for the resident batch, for models with another call signature than
         # RW_NN's (gnn_amd.rw_gnn.RW_GNN takes one ``data`` object); its lazily created layers must exist already
+        self.forward_fn_given = forward_fn is not None
+        self._train_step = None
         self.forward_fn = forward_fn if forward_fn is not None else (
             lambda: self.model(self.adj, self.feats, self.gi))
         self.bucket = FlatGradBucket(model)
@@ -117,10 +120,33 @@ class Trainer:
         self.losses = []
         self._single_loss = None
 
+    def _one_call(self) -> bool:
+        """The whole step as one library call when the model, the batch and the optimiser allow it
+        (``composite.TrainStep``); False: nothing was launched."""
+        if self.tail is None or self.forward_fn_given:
+            return False
+        model = self.model
+        if not hasattr(model, "_head_fusable") or not self.adj.is_cuda:
+            return False
+        if self._train_step is None:
+            from .composite import TrainStep
+            self._train_step = TrainStep(self)
+        st = get_structure(self.adj, self.gi)
+        drop = float(model._modules["dropout"].p) if model.training else 0.0
+        entry = self._train_step.supported(model, st, self.feats, self.y, drop)
+        if entry is None:
+            return False
+        self.loss = self._train_step.run(entry, model, st, self.feats, self.y)
+        if not self.tail.update:
+            self.tail.done = False       # the flat gradient is in the bucket; all-reduce and update follow
+        return True
+
     def fwd_bwd(self):
         # the previous step's autograd graph goes first: while it lives, so do its AccumulateGrad nodes, and the new
         # forward would reuse them, whatever stream they were created on
         self.loss = None
+        if self._one_call():
+            return
         self.bucket.release()            # optimizer.zero_grad(set_to_none=True)
         if self.tail is not None:
             self.tail.armed = True       # this backward pass ends with the optimiser's update

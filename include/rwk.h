@@ -676,6 +676,7 @@ typedef struct rwk_model_plan_t {
     int64_t stream_len_f, stream_len_b, n_partials, dz_rows, stats_blocks, spb_blocks, head_blocks, head_grad_floats;
     int64_t off_f[12];                                       /* byte offsets into forward_ws */
     int64_t off_b[8];                                        /* byte offsets into backward_ws */
+    int64_t train_step;                                      /* not 0: rwk_model_train_step serves this shape too */
 } rwk_model_plan_t;
 
 int rwk_model_plan(const rwk_model_step_t *m, rwk_model_plan_t *plan);
@@ -683,6 +684,33 @@ int rwk_model_forward(const rwk_model_step_t *m, const rwk_model_plan_t *plan, v
                       rwk_stream_t stream);
 int rwk_model_backward(const rwk_model_step_t *m, const rwk_model_plan_t *plan, const void *forward_ws,
                        void *backward_ws, const float *out, const float *d_out, float *grads, rwk_stream_t stream);
+
+/* The whole training step of rwgnn2/main.py:82-88 for one process in ONE host call: forward, cross-entropy, backward
+ * and (when the tail's param is not NULL) the Adam update - the eight launches of the captured step, here for loops
+ * that cannot replay a graph because every batch has its own shape.  Launches: rwk_x_chain_hidden_forward,
+ * rwk_fused_forward_bits, rwk_fused_reduce_stats, rwk_head_train_forward, rwk_fused_backward_bn, the transposed
+ * propagation steps, rwk_spmm_project_backward, rwk_hidden_backward_reduce_adam_head (plan->train_step 1), or, where
+ * rwk_fused_backward_bn is not built (max_step > 2; plan->train_step 2), rwk_head_train_backward,
+ * rwk_fused_backward_bits and rwk_hidden_backward_reduce_adam in their places; same bits as those calls.
+ * Served when plan->train_step is not 0 (the shape of rwk_model_forward with s > 1 and a head
+ * rwk_head_train_supported serves).  labels: int64 class index per graph.  d_loss: device float, the gradient of
+ * the loss (1.0).  loss (device float) is complete when the step has run.  grads as in rwk_model_backward;
+ * tail->grad_out (tail->n floats) receives the flat gradient in the order of the flat parameter buffer
+ * [adj_hidden | features_hidden | fc.weight | fc.bias | bn.weight | bn.bias | fc1.weight | fc1.bias | fc2.weight |
+ * fc2.bias] (tail->rest_sizes: the sizes of the last six, tail->rest_columns: where each starts in the head's
+ * gradient vector).  tail->param NULL (data-parallel step): no update, the flat gradient only. */
+typedef struct rwk_train_tail_t {
+    float *param, *exp_avg, *exp_avg_sq, *grad_out;
+    int64_t n, off_adj, off_feat, off_red, rest_off, n_rest;
+    int64_t rest_columns[8], rest_sizes[8];
+    const float *lr;
+    float beta1, beta2, eps, weight_decay;
+    int64_t *step_counters, *corr_slot;
+} rwk_train_tail_t;
+
+int rwk_model_train_step(const rwk_model_step_t *m, const rwk_model_plan_t *plan, const rwk_train_tail_t *tail,
+                         void *forward_ws, void *backward_ws, const int64_t *labels, const float *d_loss, float *out,
+                         float *loss, float *grads, rwk_stream_t stream);
 
 /* Test hook: writes the keep-mask exactly as the fused kernels draw it, one byte per element,
  * shape (L, H, S, N), for the {seed, offset} in rng. */

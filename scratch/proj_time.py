@@ -2,6 +2,9 @@
 import torch
 from gnn_amd import _lib
 
+import os
+if os.environ.get("RWK_LIB"):
+    _lib.LIB_PATH = os.environ["RWK_LIB"]
 lib = _lib.load()
 dev = torch.device("cuda:0")
 stream = _lib.current_stream(dev)

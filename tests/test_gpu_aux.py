@@ -21,9 +21,13 @@ def dev():
 def stream_kernels_without_dropout(monkeypatch):
     """This file exercises the launch structure of the training step on the stream kernels (statistics hand-over,
     folded head finish, optimiser in the last launch) with and without dropout; without dropout the layer would
-    otherwise take the Gram-matrix path, which has its own tests (test_gpu_gram.py)."""
+    otherwise take the Gram-matrix path, which has its own tests (test_gpu_gram.py).  The step goes through autograd
+    here: the one-call step (composite.TrainStep), which replaces it where it applies, is compared with this path
+    in test_gpu_composite.py."""
+    import gnn_amd.composite as comp
     import gnn_amd.function as fn
     monkeypatch.setattr(fn, "GRAM_FAST_PATH", False)
+    monkeypatch.setattr(comp, "ONE_CALL_TRAIN_STEP", False)
 
 
 @pytest.mark.parametrize("p,v", [(1, 7), (32, 640), (33, 5), (1203, 640), (5000, 70)])

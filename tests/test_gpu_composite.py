@@ -113,3 +113,79 @@ def test_composite_step_declines_what_it_does_not_serve(monkeypatch):
     m(adj, feats_g, gi).sum().backward()
     assert feats_g.grad is not None and not calls
     assert m(adj, feats, gi).shape == (32, 2) and calls == [1]
+
+
+TRAIN_CASES = [(64, (20, 60), None, 16, 5, 4, 2, False, 0.2, False),
+               (40, (5, 90), 3, 16, 5, 4, 3, True, 0.3, False),
+               (33, (2, 40), None, 8, 3, 4, 4, False, 0.5, True),
+               (64, (20, 60), None, 16, 5, 4, 2, False, 0.0, False)]
+
+
+def _train(dev, case, one_call, monkeypatch, world=1, graph=False):
+    import gnn_amd.composite as comp
+    import gnn_amd.function as fn
+    from gnn_amd import RW_NN
+    from gnn_amd.structure import clear_structure_cache
+    from gnn_amd.trainer import Trainer
+    graphs, nodes, n_feat, h, s, d, steps_l, normalize, p, weighted = case
+    monkeypatch.setattr(comp, "ONE_CALL_TRAIN_STEP", one_call)
+    if p == 0.0:
+        monkeypatch.setattr(fn, "GRAM_FAST_PATH", False)
+    clear_structure_cache()
+    adj, feats, gi, y = _batch(dev, graphs, nodes, n_feat, weighted, seed=7)
+    torch.manual_seed(1)
+    m = RW_NN(feats.shape[1], steps_l, h, s, d, 32, normalize, 3, p, dev).to(dev).train()
+    m.seed_dropout(99)
+    tr = Trainer(m, (adj, feats, gi, y % 3), world)
+    calls = []
+    real = comp.TrainStep.run
+    monkeypatch.setattr(comp.TrainStep, "run", lambda self, *a: (calls.append(1), real(self, *a))[1])
+    losses, grads = [], []
+    if graph:
+        tr.capture(steps_per_graph=2)
+        for _ in range(2):
+            tr.step_graph()
+            losses.append(tr.loss.detach().clone())
+        tr.run_steps(4)
+        losses += [v.detach().clone() for v in tr.losses]
+    else:
+        for _ in range(4):
+            tr.step_eager()
+            losses.append(tr.loss.detach().clone())
+            grads.append([q.grad.detach().clone() for q in m.parameters()])
+    torch.cuda.synchronize()
+    state = [q.detach().clone() for q in m.parameters()] + [
+        tr.opt.exp_avg.clone(), tr.opt.exp_avg_sq.clone(), tr.bucket.flat.clone(), m.bn.running_mean.clone(),
+        m.bn.running_var.clone(), m.bn.num_batches_tracked.clone(), m._rng_state.clone()]
+    return losses, grads, state, len(calls)
+
+
+@pytest.mark.parametrize("case", TRAIN_CASES, ids=lambda c: "g%d_f%s_h%d_s%d_l%d_p%s%s" % (
+    c[0], c[2], c[3], c[4], c[6], c[8], "_w" if c[9] else ""))
+def test_one_call_train_step_equals_the_autograd_step(case, monkeypatch):
+    """``rwk_model_train_step`` against ``Trainer``'s step through autograd: losses, per-parameter gradients, flat
+    gradient, parameters, moments, running statistics and generator state after four eager steps."""
+    dev = _dev()
+    l1, g1, s1, n1 = _train(dev, case, True, monkeypatch)
+    l0, g0, s0, n0 = _train(dev, case, False, monkeypatch)
+    assert n1 >= 4 and n0 == 0
+    assert [float(v) for v in l1] == [float(v) for v in l0] and all(np.isfinite(float(v)) for v in l1)
+    for ga, gb in zip(g1, g0):
+        for a, b in zip(ga, gb):
+            assert a.shape == b.shape and torch.equal(a, b)
+    for a, b in zip(s1, s0):
+        assert torch.equal(a, b)
+
+
+def test_one_call_train_step_under_capture_and_in_the_data_parallel_shape(monkeypatch):
+    """Captured (single and multi-step replays) and with the update left to a separate launch (the shape of a
+    data-parallel step, here with one process): same bits as the autograd step."""
+    dev = _dev()
+    case = TRAIN_CASES[0]
+    for kw in (dict(graph=True), dict(world=2)):
+        l1, _, s1, n1 = _train(dev, case, True, monkeypatch, **kw)
+        l0, _, s0, n0 = _train(dev, case, False, monkeypatch, **kw)
+        assert n1 > 0 and n0 == 0
+        assert [float(v) for v in l1] == [float(v) for v in l0]
+        for a, b in zip(s1, s0):
+            assert torch.equal(a, b)
