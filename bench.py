@@ -412,8 +412,10 @@ class StreamBench:
 
     def describe(self):
         return ("pool of %d distinct batches x %d graphs (%d nodes) resident as one data set; every batch assembled "
-                "inside the timed region (one upload + one launch on a side stream, structure included), steps "
-                "launched eagerly" % (len(self.id_lists), self.per_batch, self.nodes))
+                "inside the timed region (one upload per pass + one launch per batch on a side stream, structure "
+                "included), steps launched eagerly%s" % (
+                    len(self.id_lists), self.per_batch, self.nodes,
+                    ", each as one library call on the slot's buffers" if self.tr.raw_steps else ""))
 
 
 def stream_extra(config, dev, pool_batches=31, steps=62, warmup=8):
@@ -426,6 +428,21 @@ def stream_extra(config, dev, pool_batches=31, steps=62, warmup=8):
     return {"config": config, "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 4),
             "device_ms_per_step": round(dev_ms / steps, 4),
             "graphs_per_s": round(sb.per_batch * steps / elapsed, 1), "what": sb.describe()}
+
+
+def eager_step_extra(batch_t, hp, dev, steps=200, warmup=50):
+    """Trainer.step_eager on the resident batch: the whole step as one library call, no graph replay."""
+    from gnn_amd.trainer import Trainer
+    tr = Trainer(_new_model(hp, dev), batch_t)
+    for _ in range(warmup):
+        tr.step_eager()
+    elapsed, dev_ms = _timed(lambda n: [tr.step_eager() for _ in range(n)], steps)
+    return {"steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "device_ms_per_step": round(dev_ms / steps, 4),
+            "graphs_per_s": round(int(batch_t[3].numel()) * steps / elapsed, 1),
+            "one_call": bool(tr._train_step is not None and tr.tail is not None and tr.tail.head_folds > 0),
+            "what": "the headline step launched eagerly, not replayed: forward, loss, backward and Adam in one "
+                    "library call (rwk_model_train_step), the same eight launches"}
 
 
 def cpu_baseline(batch, hp, n_graphs, budget_s=20.0):
@@ -701,6 +718,8 @@ def main():
             try:
                 result["distinct_batches"] = distinct_batches_epoch(args.config, hp, dev, 16)
                 result["stream_h64_stream"] = stream_extra("stream_h64", dev)
+                result["stream_proteins1024"] = stream_extra("proteins1024", dev, steps=124, warmup=31)
+                result["eager_one_call_step"] = eager_step_extra(batch_t, hp, dev)
             except Exception as exc:                      # the extras never cost the headline
                 result["extras_error"] = "%s: %s" % (type(exc).__name__, str(exc)[:300])
         if not args.no_cpu_baseline and world == 1:

@@ -228,6 +228,74 @@ class TrainStep:
             return None
         return entry
 
+    # ---- batches that live in the preallocated slots of a DeviceDataset (StreamTrainer) ------------------------
+    def slots_supported(self, model, dataset) -> bool:
+        """Once per pass: whether :meth:`run_slot` may serve the batches of ``dataset`` (each batch is still checked
+        by ``rwk_model_plan``: a graph too large for the LDS, say, sends that one batch through the tensors)."""
+        tr = self.trainer
+        from . import function as fn
+        drop = float(model._modules["dropout"].p) if model.training else 0.0
+        if not (ONE_CALL_TRAIN_STEP and tr.tail is not None and tr.loss_in_head and not tr.forward_fn_given
+                and hasattr(model, "_head_fusable") and model.training
+                and fn.FOLD_HEAD_FINISH and fn.MERGED_LAUNCHES and fn.FUSED_STEP_LAUNCHES and fn.GRAPH_X_CHAIN
+                and not (drop == 0.0 and fn.GRAM_FAST_PATH) and drop < 1.0 and torch.is_grad_enabled()
+                and dataset.symmetric and 1 <= dataset.n_feat <= 15
+                and model._parameters["features_hidden"].shape[2] == 4
+                and model._modules["fc"].in_features == dataset.n_feat):
+            return False
+        for p in tr.bucket.params:
+            if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None) \
+                    or not p.is_contiguous():
+                return False
+        return True
+
+    def run_slot(self, model, dataset, slot, meta) -> bool:
+        """The step on the batch that ``DeviceDataset.launch_planned`` left in ``slot`` (``meta``: its entry of the
+        plan), straight from the slot's buffers: no tensor, no structure object, one ``rwk_model_plan`` and one
+        ``rwk_model_train_step`` call.  False (nothing launched): the calls do not serve this batch."""
+        from .structure import spmm_schedule
+        lib = _lib.load()
+        tr = self.trainer
+        b, n, nnz, max_degree, fits16, _, y_lo, y_hi, max_graph = meta
+        if nnz <= 0 or max_degree > 64:
+            return False
+        drop = float(model._modules["dropout"].p)
+        m = getattr(slot, "step", None)
+        if m is None:
+            m = ModelStep()                    # the slot's buffers never move: their addresses are set once
+            m.features = slot.feats.data_ptr()
+            m.crow = m.crow_t = slot.crow.data_ptr()
+            m.col = m.col_t = slot.col.data_ptr()
+            m.val = None if dataset.unit_values else slot.val.data_ptr()
+            m.unit_values_t = int(bool(dataset.unit_values))
+            m.seg_ptr, m.gid, m.counts_f32 = slot.seg_ptr.data_ptr(), slot.gid.data_ptr(), slot.counts_f32.data_ptr()
+            m.f, m.d = dataset.n_feat, 4
+            slot.step = m
+            slot.plan = ModelPlan()
+        mods = model._modules
+        bn = mods["bn"]
+        h, s, _ = model._parameters["features_hidden"].shape
+        m.n, m.nnz, m.n_graphs, m.max_graph_nodes = n, nnz, b, max_graph
+        m.max_degree = m.max_degree_t = max_degree
+        m.col16_t = slot.col16.data_ptr() if (fits16 and slot.col16 is not None) else None
+        # (a lean assembly leaves the value array of an unweighted batch with compact columns unwritten)
+        m.val_t = None if (m.col16_t and dataset.unit_values) else slot.val.data_ptr()
+        m.long_threshold_t = int(spmm_schedule(n, nnz, max_degree)[1] or 0)
+        m.h, m.s, m.max_step = h, s, int(model.max_step)
+        m.p, m.nc = mods["fc1"].out_features, mods["fc2"].out_features
+        m.normalize = int(bool(model.normalize))
+        m.drop_p, m.momentum, m.eps = drop, float(bn.momentum), float(bn.eps)
+        plan = slot.plan
+        if bn.num_features != h * m.max_step or not bn.affine or not bn.track_running_stats or bn.momentum is None \
+                or not model.fused_head or b < 2:
+            return False
+        if lib.rwk_model_plan(ctypes.byref(m), ctypes.byref(plan)) != 0 or not plan.train_step:
+            return False
+        if y_lo < 0 or y_hi >= m.nc:
+            raise IndexError(f"Target {y_lo if y_lo < 0 else y_hi} is out of bounds for {m.nc} classes")
+        tr.loss = self._launch(lib, model, m, plan, slot.y.data_ptr(), b, slot.feats.device)
+        return True
+
     def _tail(self, lib, shape):
         tail, o = self.trainer.tail, self.trainer.opt
         t = self.tail_struct
@@ -257,22 +325,23 @@ class TrainStep:
     def run(self, entry, model, st, feats, y):
         """Queue the step; returns the loss tensor (complete once the step has run)."""
         from .head import check_labels
-        lib = _lib.load()
-        tr = self.trainer
         m, plan, _, _ = entry
-        dev = feats.device
         check_labels(y, m.nc)
+        m.features = feats.data_ptr()
+        return self._launch(_lib.load(), model, m, plan, y.data_ptr(), st.n_graphs, feats.device)
+
+    def _launch(self, lib, model, m, plan, labels_ptr, n_graphs, dev):
+        tr = self.trainer
         if m.drop_p > 0.0 and not model._rng_seeded:
             model._seed_from_torch()
         with _lib.device_guard(dev):
             fws = self._room(0, plan.forward_bytes, torch.uint8, dev)
             bws = self._room(1, plan.backward_bytes, torch.uint8, dev)
             grads = self._room(2, plan.grad_floats, torch.float32, dev)
-            out = self._room(3, st.n_graphs * m.nc, torch.float32, dev)
+            out = self._room(3, n_graphs * m.nc, torch.float32, dev)
             loss = torch.empty((), dtype=torch.float32, device=dev)
             mods, own = model._modules, model._parameters
             fc, bn, fc1, fc2 = (mods[k]._parameters for k in ("fc", "bn", "fc1", "fc2"))
-            m.features = feats.data_ptr()
             m.adj_hidden, m.features_hidden = own["adj_hidden"].data_ptr(), own["features_hidden"].data_ptr()
             m.fc_w, m.fc_b = fc["weight"].data_ptr(), fc["bias"].data_ptr()
             m.bn_w, m.bn_b = bn["weight"].data_ptr(), bn["bias"].data_ptr()
@@ -285,7 +354,7 @@ class TrainStep:
             fold = plan.train_step == 1
             t = self._tail(lib, "head" if fold else "plain")
             _lib.check(lib.rwk_model_train_step(ctypes.byref(m), ctypes.byref(plan), ctypes.byref(t), fws.data_ptr(),
-                                                bws.data_ptr(), y.data_ptr(), tr._one.data_ptr(), out.data_ptr(),
+                                                bws.data_ptr(), labels_ptr, tr._one.data_ptr(), out.data_ptr(),
                                                 loss.data_ptr(), grads.data_ptr(), _lib.current_stream(dev)),
                        "rwk_model_train_step")
         tr.tail.after_launch(fold)

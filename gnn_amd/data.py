@@ -56,7 +56,7 @@ def load_data(ds_name: str, use_node_labels: bool, root: str = "datasets"):
 class _Slot:
     """Preallocated output buffers of one batch (:meth:`DeviceDataset.make_slots`)."""
     __slots__ = ("idx", "vals", "feats", "gi", "y", "crow", "col", "val", "col16", "gid", "seg_ptr", "counts",
-                 "counts_f32", "cap")
+                 "counts_f32", "cap", "step", "plan")
 
 
 class DeviceDataset:
@@ -223,58 +223,81 @@ class DeviceDataset:
 
     def batch_planned(self, plan: "BatchPlan", i: int, slot: "_Slot" = None):
         """Batch ``i`` of a :meth:`plan`: one launch (``rwk_batch_build``) on the current stream."""
-        from .structure import GraphStructure, register_structure
-        lib = _lib.load()
         dev = self.device
         b, n, nnz, max_degree, fits16, off, y_lo, y_hi, max_graph = plan.metas[i]
         f = self.n_feat
         with _lib.device_guard(dev):
             if slot is None:
-                idx = torch.empty((2, nnz), dtype=torch.int64, device=dev)
-                vals = torch.empty(nnz, dtype=torch.float32, device=dev)
-                feats = torch.empty((n, f), dtype=torch.float32, device=dev)
-                gi = torch.empty(n, dtype=torch.int64, device=dev)
-                yy = torch.empty(b, dtype=torch.int64, device=dev)
-                crow = torch.empty(n + 1, dtype=torch.int32, device=dev)
-                col = torch.empty(nnz, dtype=torch.int32, device=dev)
-                val = torch.empty(nnz, dtype=torch.float32, device=dev)
-                col16 = torch.empty(nnz, dtype=torch.int16, device=dev) if (fits16 and nnz) else None
-                gid = torch.empty(n, dtype=torch.int32, device=dev)
-                seg_ptr = torch.empty(b + 1, dtype=torch.int32, device=dev)
-                counts = torch.empty(b, dtype=torch.int64, device=dev)
-                counts_f32 = torch.empty(b, dtype=torch.float32, device=dev)
-            else:
-                cb, cn, ce = slot.cap
-                if b > cb or n > cn or nnz > ce:
-                    raise ValueError(f"batch of {b} graphs, {n} nodes, {nnz} entries exceeds the slot ({cb}, {cn}, {ce})")
-                idx = slot.idx[:2 * nnz].view(2, nnz)
-                vals = slot.vals[:nnz]
-                feats = slot.feats[:n * f].view(n, f)
-                gi, yy = slot.gi[:n], slot.y[:b]
-                crow, col, val = slot.crow[:n + 1], slot.col[:nnz], slot.val[:nnz]
-                col16 = slot.col16[:nnz] if (fits16 and nnz) else None
-                gid, seg_ptr = slot.gid[:n], slot.seg_ptr[:b + 1]
-                counts, counts_f32 = slot.counts[:b], slot.counts_f32[:b]
-            nz = nnz > 0
-            rows_p = idx.data_ptr() if nz else None
-            _lib.check(lib.rwk_batch_build(
-                self.row_ptr.data_ptr(), _lib.ptr(self.col), _lib.ptr(self.val), self.features.data_ptr(), f,
-                self.y.data_ptr(), plan.tables.data_ptr() + 8 * off, b, n, nnz,
-                rows_p, rows_p + 8 * nnz if nz else None, vals.data_ptr() if nz else None,
-                feats.data_ptr() if f else None, gi.data_ptr(), yy.data_ptr(), crow.data_ptr(),
-                col.data_ptr() if nz else None, val.data_ptr() if nz else None, _lib.ptr(col16), gid.data_ptr(),
-                seg_ptr.data_ptr(), counts.data_ptr(), counts_f32.data_ptr(), _lib.current_stream(dev)),
-                "rwk_batch_build")
-            adj = torch.sparse_coo_tensor(idx, vals, (n, n), check_invariants=False)
-            yy._rwk_label_range = (yy._version, y_lo, y_hi)      # known on the host (gnn_amd.head.check_labels)
-            if self.symmetric:
-                st = GraphStructure.from_parts(dev, n, nnz, b, crow, col, val, col16, self.unit_values, max_degree,
-                                               gid, seg_ptr, counts, counts_f32)
-                st.plan_tables = plan.tables       # the launch reads them asynchronously
-                st.eval_facts = (max_graph, True)  # largest graph; block-diagonal by construction (gnn_amd.eval)
-                register_structure(adj, gi, st)
-            # an asymmetric data set needs the transposed CSR as well: get_structure builds it on first use
-            return adj, feats, gi, yy
+                slot = _Slot()
+                slot.cap = (b, n, nnz)
+                slot.idx = torch.empty(2 * nnz, dtype=torch.int64, device=dev)
+                slot.vals = torch.empty(nnz, dtype=torch.float32, device=dev)
+                slot.feats = torch.empty(n * f, dtype=torch.float32, device=dev)
+                slot.gi = torch.empty(n, dtype=torch.int64, device=dev)
+                slot.y = torch.empty(b, dtype=torch.int64, device=dev)
+                slot.crow = torch.empty(n + 1, dtype=torch.int32, device=dev)
+                slot.col = torch.empty(nnz, dtype=torch.int32, device=dev)
+                slot.val = torch.empty(nnz, dtype=torch.float32, device=dev)
+                slot.col16 = torch.empty(nnz, dtype=torch.int16, device=dev) if (fits16 and nnz) else None
+                slot.gid = torch.empty(n, dtype=torch.int32, device=dev)
+                slot.seg_ptr = torch.empty(b + 1, dtype=torch.int32, device=dev)
+                slot.counts = torch.empty(b, dtype=torch.int64, device=dev)
+                slot.counts_f32 = torch.empty(b, dtype=torch.float32, device=dev)
+            self.launch_planned(plan, i, slot, _lib.current_stream(dev))
+            return self.wrap_slot(plan, i, slot)
+
+    def launch_planned(self, plan: "BatchPlan", i: int, slot: "_Slot", stream, lean: bool = False):
+        """The launch alone: batch ``i`` of the plan into the slot's buffers, queued on ``stream`` (a raw stream
+        handle; torch's current stream is left alone).  :meth:`wrap_slot` gives the tensors of the batch; a consumer
+        that works on the buffers themselves (``gnn_amd.composite.TrainStep.run_slot``) needs none, and with ``lean``
+        the arrays only the tensors are made of stay unwritten (the COO copy of the adjacency, the int64 graph ids,
+        the int64 graph sizes, the value array of an unweighted batch with compact columns: 25 of the 45 MB a
+        1024-graph batch of proteins-sized graphs writes)."""
+        b, n, nnz, max_degree, fits16, off, y_lo, y_hi, max_graph = plan.metas[i]
+        cb, cn, ce = slot.cap
+        if b > cb or n > cn or nnz > ce:
+            raise ValueError(f"batch of {b} graphs, {n} nodes, {nnz} entries exceeds the slot ({cb}, {cn}, {ce})")
+        f = self.n_feat
+        nz = nnz > 0
+        coo = nz and not lean
+        compact = fits16 and nz and slot.col16 is not None
+        rows_p = slot.idx.data_ptr() if coo else None
+        _lib.check(_lib.load().rwk_batch_build(
+            self.row_ptr.data_ptr(), _lib.ptr(self.col), _lib.ptr(self.val), self.features.data_ptr(), f,
+            self.y.data_ptr(), plan.tables.data_ptr() + 8 * off, b, n, nnz,
+            rows_p, rows_p + 8 * nnz if coo else None, slot.vals.data_ptr() if coo else None,
+            slot.feats.data_ptr() if f else None, None if lean else slot.gi.data_ptr(), slot.y.data_ptr(),
+            slot.crow.data_ptr(), slot.col.data_ptr() if nz else None,
+            slot.val.data_ptr() if (nz and not (lean and compact and self.unit_values)) else None,
+            slot.col16.data_ptr() if compact else None, slot.gid.data_ptr(),
+            slot.seg_ptr.data_ptr(), None if lean else slot.counts.data_ptr(), slot.counts_f32.data_ptr(), stream),
+            "rwk_batch_build")
+
+    def wrap_slot(self, plan: "BatchPlan", i: int, slot: "_Slot"):
+        """(adj, features, graph_indicator, y) over the slot's buffers after :meth:`launch_planned`, the structure
+        registered (host work only)."""
+        from .structure import GraphStructure, register_structure
+        dev = self.device
+        b, n, nnz, max_degree, fits16, off, y_lo, y_hi, max_graph = plan.metas[i]
+        f = self.n_feat
+        idx = slot.idx[:2 * nnz].view(2, nnz)
+        vals = slot.vals[:nnz]
+        feats = slot.feats[:n * f].view(n, f)
+        gi, yy = slot.gi[:n], slot.y[:b]
+        crow, col, val = slot.crow[:n + 1], slot.col[:nnz], slot.val[:nnz]
+        col16 = slot.col16[:nnz] if (fits16 and nnz and slot.col16 is not None) else None
+        gid, seg_ptr = slot.gid[:n], slot.seg_ptr[:b + 1]
+        counts, counts_f32 = slot.counts[:b], slot.counts_f32[:b]
+        adj = torch.sparse_coo_tensor(idx, vals, (n, n), check_invariants=False)
+        yy._rwk_label_range = (yy._version, y_lo, y_hi)      # known on the host (gnn_amd.head.check_labels)
+        if self.symmetric:
+            st = GraphStructure.from_parts(dev, n, nnz, b, crow, col, val, col16, self.unit_values, max_degree,
+                                           gid, seg_ptr, counts, counts_f32)
+            st.plan_tables = plan.tables       # the launch reads them asynchronously
+            st.eval_facts = (max_graph, True)  # largest graph; block-diagonal by construction (gnn_amd.eval)
+            register_structure(adj, gi, st)
+        # an asymmetric data set needs the transposed CSR as well: get_structure builds it on first use
+        return adj, feats, gi, yy
 
 
 class BatchPlan:

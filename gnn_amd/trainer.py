@@ -426,18 +426,25 @@ class StreamTrainer(Trainer):
         first = dataset.batch(list(range(min(2, dataset.n_graphs))))
         super().__init__(model, first, **kw)
         self.pass_losses = []
+        self.raw_steps = 0                      # steps that ran as one library call on a slot's buffers
 
-    def _prepare(self, plan, i, k):
-        """Issue the assembly of batch ``i`` of the plan into slot ``k``; returns (batch, ready event or None)."""
-        if self.build_stream is None:
-            return self.dataset.batch_planned(plan, i, slot=self.slots[k]), None
-        with torch.cuda.stream(self.build_stream):
-            if self.slot_free[k] is not None:
-                self.build_stream.wait_event(self.slot_free[k])
-            batch = self.dataset.batch_planned(plan, i, slot=self.slots[k])
+    def _prepare(self, plan, i, k, raw: bool):
+        """Issue the assembly of batch ``i`` of the plan into slot ``k`` (on the side stream when there is one);
+        returns (batch tensors, or None when ``raw``: the step then reads the slot's buffers itself; ready event or
+        None)."""
+        from . import _lib
+        ds = self.dataset
+        side = self.build_stream
+        if side is not None and self.slot_free[k] is not None:
+            side.wait_event(self.slot_free[k])
+        stream = side.cuda_stream if side is not None else _lib.current_stream(ds.device)
+        with _lib.device_guard(ds.device):
+            ds.launch_planned(plan, i, self.slots[k], stream, lean=raw)
+        ready = None
+        if side is not None:
             ready = torch.cuda.Event()
-            ready.record(self.build_stream)
-        return batch, ready
+            ready.record(side)
+        return (None if raw else ds.wrap_slot(plan, i, self.slots[k])), ready
 
     def run_pass(self, id_lists, keep_losses: bool = True):
         """One training step per entry of ``id_lists`` (lists of graph ids of the data set), in order.  Returns the
@@ -451,17 +458,35 @@ class StreamTrainer(Trainer):
         if self.build_stream is not None:
             self.build_stream.wait_stream(main)
         side = self.build_stream is not None
-        nxt = self._prepare(plan, 0, 0)
+        if self._train_step is None and self.tail is not None:
+            from .composite import TrainStep
+            self._train_step = TrainStep(self)
+        # the whole step as one library call on the slot's buffers (no tensors per batch) where that applies
+        raw = self._train_step is not None and self.world == 1 and \
+            self._train_step.slots_supported(self.model, self.dataset)
+        nxt = self._prepare(plan, 0, 0, raw)
         for t in range(len(id_lists)):
             batch, ready = nxt
             if side and t + 1 < len(id_lists):
-                nxt = self._prepare(plan, t + 1, (t + 1) % depth)
+                nxt = self._prepare(plan, t + 1, (t + 1) % depth, raw)
             if ready is not None:
                 main.wait_event(ready)
-            self.adj, self.feats, self.gi, self.y = batch
-            self.fwd_bwd()
-            if self.world > 1:
-                self._all_reduce()
+            self.loss = None
+            if not (raw and self._train_step.run_slot(self.model, self.dataset, self.slots[t % depth],
+                                                      plan.metas[t])):
+                if batch is None:
+                    # (rare: a batch the one-call step does not serve) the lean assembly left the tensors' own
+                    # arrays unwritten: assemble again, in full, in front of the step
+                    from . import _lib
+                    self.dataset.launch_planned(plan, t, self.slots[t % depth],
+                                                _lib.current_stream(self.dataset.device))
+                    batch = self.dataset.wrap_slot(plan, t, self.slots[t % depth])
+                self.adj, self.feats, self.gi, self.y = batch
+                self.fwd_bwd()
+                if self.world > 1:
+                    self._all_reduce()
+            else:
+                self.raw_steps += 1
             self._opt_step()
             if side:
                 done = torch.cuda.Event()
@@ -469,7 +494,7 @@ class StreamTrainer(Trainer):
                 self.slot_free[t % depth] = done
             elif t + 1 < len(id_lists):
                 # same stream: the next assembly is ordered behind this step by the stream itself
-                nxt = self._prepare(plan, t + 1, (t + 1) % depth)
+                nxt = self._prepare(plan, t + 1, (t + 1) % depth, raw)
             if keep_losses:
                 losses.append(self.loss.detach())
         self.pass_losses = losses
