@@ -523,8 +523,16 @@ def main():
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # RWK_REHEARSE_RCCL=1 (with --dp-shape 2): a ONE-rank process group on the real collective library, and every
+    # collective call of the multi-rank path issued on it - what a box with a single GPU can check of that path
+    # (initialisation, the averaging all-reduce on the launch stream, its capture, the barriers, the shutdown).
+    rehearse = world == 1 and os.environ.get("RWK_REHEARSE_RCCL", "0") == "1"
+    dist_on = world > 1 or rehearse
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -578,7 +586,7 @@ def main():
     if args.stream:
         # never-repeating batches: assembly inside the timed region, eager steps (StreamTrainer)
         stream_bench = StreamBench(args.config, hp, dev, args.pool_batches, seed=1 + rank, optimizer=args.optimizer,
-                                   world=world, sync_before_all_reduce=backend != "nccl")
+                                   world=shape_world, sync_before_all_reduce=backend != "nccl")
         model, tr = stream_bench.tr.model, stream_bench.tr
         broadcast_parameters(model)
         run_steps = stream_bench.run
@@ -603,7 +611,7 @@ def main():
         model = _new_model(hp, dev, 1234 + rank)
         broadcast_parameters(model)
         tr = Trainer(model, batch_t, shape_world, args.optimizer, sync_before_all_reduce=backend != "nccl",
-                     capture_collective=capture_collective and world > 1)
+                     capture_collective=capture_collective and dist_on)
         if args.mode == "graph":
             try:
                 spg = args.steps_per_graph if (shape_world == 1 and args.steps_per_graph > 1) else 1
@@ -633,7 +641,7 @@ def main():
     else:
         for _ in range(args.warmup):
             step()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -650,12 +658,12 @@ def main():
     while not ev1.query():
         pass
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     device_ms = ev0.elapsed_time(ev1)
     n_graphs_total = graphs_per_step
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -694,7 +702,8 @@ def main():
             "device_ms_per_step": round(device_ms / args.steps, 4),
         }
         if shape_world != world:
-            result["config"]["launch"] += f"; step in the shape of a {shape_world}-rank run (no process group)"
+            result["config"]["launch"] += f"; step in the shape of a {shape_world}-rank run (%s)" % (
+                "one-rank %s process group, every collective issued" % backend if rehearse else "no process group")
         if phases is not None:
             result["phases"] = phases
         if tr.capture_note:
@@ -725,7 +734,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(batch, hp, args.cpu_sample_graphs)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

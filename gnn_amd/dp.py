@@ -10,6 +10,7 @@ The reference has no multi-device path; batch-norm statistics stay per rank.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Sequence, Tuple
 
 import numpy as np
@@ -103,8 +104,8 @@ class FlatGradBucket:
         if not dist.is_available() or not dist.is_initialized():
             return
         world = dist.get_world_size(group)
-        if world == 1:
-            return
+        if world == 1 and os.environ.get("RWK_REHEARSE_RCCL", "0") != "1":
+            return       # (the rehearsal switch issues the collective on a one-rank group: bench.py)
         if average and self.flat.is_cuda and dist.get_backend(group) == "nccl" and self._avg_ok is not False:
             # RCCL averages inside the collective: no separate division launch
             try:
