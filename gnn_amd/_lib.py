@@ -120,6 +120,12 @@ SIGNATURES = {
     "rwk_x_chain_lds": (_I64, [_I64, _I64, _I64]),
     "rwk_x_chain_hidden_forward": (c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _I64,
                                            _I64, _P, _P, _P, _P, _P]),
+    "rwk_graph_chain_forward_lds": (_I64, [_I64, _I64, _I64]),
+    "rwk_graph_chain_forward": (c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _I64,
+                                        _I64, _P, _P, _P, _P, _P]),
+    "rwk_graph_chain_backward_lds": (_I64, [_I64, _I64]),
+    "rwk_graph_chain_backward": (c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P,
+                                         _I64, _I64, _P, _P]),
     "rwk_gather_chunks": (c_int, [_P, _P, _I64, _P, _P]),
     "rwk_adam_n_counters": (_I64, [_I64]),
     "rwk_adam_step": (c_int, [_P, _P, _P, _P, _I64, _P, c_float, c_float, c_float, c_float, _P, _P]),

@@ -46,6 +46,14 @@ GRAM_FAST_PATH = True
 #: every propagation step and the hidden graphs in ONE launch, one workgroup per graph (csrc/rwk_eval.hip), instead of
 #: the projection launch followed by one SpMM launch per step; False keeps those (tests compare the two)
 GRAPH_X_CHAIN = True
+#: block-diagonal batches of large graphs (more than GRAPH_CHAIN_MIN_NODES nodes, or rows of more than 64 stored
+#: entries): the propagation chain and its backward per graph in LDS (csrc/rwk_chain.hip); False keeps the SpMM launches
+GRAPH_CHAIN = True
+GRAPH_CHAIN_MIN_NODES = 1024
+#: ... and enough of them to give every CU a graph: a workgroup walks its graph on ONE CU (a step of a 3000-node graph
+#: takes 6-10 us there, LDS-bound), so 64 such graphs are served as fast by SpMM launches that spread every step over
+#: the whole chip (38 against 41 us for four steps), 256 of them faster by the chain (46 against 61 us)
+GRAPH_CHAIN_MIN_GRAPHS = 128
 #: graphs beyond this many nodes on average stay on the stream kernels (a Gram wavefront walks its graph alone)
 GRAM_MAX_MEAN_NODES = 4096
 
@@ -128,14 +136,33 @@ class _RWKernelLayer(torch.autograd.Function):
             fuse_step = (projected and d == 4 and steps >= 2 and MERGED_LAUNCHES and FUSED_STEP_LAUNCHES
                          and 4 * f_in + 4 <= 64 and st.nnz > 0
                          and use_tile_kernel(n, st.nnz, st.csr_t.max_degree, 4))
-            x_chain = False
-            # (rows of more than 64 stored entries are summed in tree order by the tile SpMM: left to it)
+            x_chain = big_chain = chain_bwd = False
+            max_nodes = 0
             if (projected and d == 4 and MERGED_LAUNCHES and GRAPH_X_CHAIN and st.perm is None and st.nnz > 0
-                    and st.csr.max_degree <= 64):
+                    and st.csr.col is not None):
                 from .eval import _facts
                 max_nodes, block_diagonal = _facts(st)
-                x_chain = block_diagonal and bool(lib.rwk_x_chain_lds(f_in, max_nodes, s))
-            if x_chain:                                                          # model.py:39-43,55-56 in one launch
+                # graphs of thousands of nodes and rows of hundreds of entries: a workgroup of 1024 threads per graph,
+                # hub rows by a wavefront each (rwk_chain.hip); small sparse graphs: 256 threads, a thread per row
+                big = max_nodes > GRAPH_CHAIN_MIN_NODES or max(st.csr.max_degree, st.csr_t.max_degree) > 64
+                if block_diagonal and big and GRAPH_CHAIN and g >= GRAPH_CHAIN_MIN_GRAPHS:
+                    big_chain = bool(lib.rwk_graph_chain_forward_lds(f_in, max_nodes, s))
+                    chain_bwd = bool(fuse_step and st.csr_t.col is not None
+                                     and lib.rwk_graph_chain_backward_lds(f_in, max_nodes))
+                elif block_diagonal and st.csr.max_degree <= 64:
+                    # (rows of more than 64 stored entries are summed in tree order by the tile SpMM: left to it)
+                    x_chain = bool(lib.rwk_x_chain_lds(f_in, max_nodes, s))
+            if big_chain:                                                        # model.py:39-43,55-56 in one launch
+                w_c = fc_weight.detach().contiguous()
+                csr = st.csr
+                _lib.check(lib.rwk_graph_chain_forward(
+                    inp_c.data_ptr(), w_c.data_ptr(), fc_bias.detach().contiguous().data_ptr(), n, f_in,
+                    csr.crow.data_ptr(), _lib.ptr(csr.col), None if csr.unit_values else _lib.ptr(csr.val),
+                    st.seg_ptr.data_ptr(), g, max_nodes, steps, xs.data_ptr(), _lib.ptr(adj_hidden_c),
+                    feat_c.data_ptr(), n_hidden, s, ah.data_ptr(), z.data_ptr(), rng_in, _lib.ptr(rng_used), stream),
+                    "rwk_graph_chain_forward")
+                x_chain = True                                                   # no SpMM launches below
+            elif x_chain:                                                        # the same for small sparse graphs
                 w_c = fc_weight.detach().contiguous()
                 csr = st.csr
                 _lib.check(lib.rwk_x_chain_hidden_forward(
@@ -178,6 +205,7 @@ class _RWKernelLayer(torch.autograd.Function):
                 ctx.st = st
                 ctx.cfg = (steps, bool(normalize), drop, projected)
                 ctx.fuse_step = fuse_step
+                ctx.chain_bwd = (chain_bwd, max_nodes)
                 ctx.handoff = handoff
                 ctx.gram = True
                 ctx.save_for_backward(xs, z, ah, adj_hidden_c, rng_used, inp_c if projected else None, w_c, gram_c)
@@ -220,6 +248,7 @@ class _RWKernelLayer(torch.autograd.Function):
         ctx.st = st
         ctx.cfg = (steps, bool(normalize), drop, projected)
         ctx.fuse_step = fuse_step
+        ctx.chain_bwd = (chain_bwd, max_nodes)
         ctx.handoff = handoff
         ctx.gram = False
         ctx.save_for_backward(xs, z, ah, adj_hidden_c, rng_used, inp_c if projected else None, w_c, keep)
@@ -282,8 +311,9 @@ class _RWKernelLayer(torch.autograd.Function):
                 dz_rows = plan["dz_rows32"]
                 dz = torch.empty((dz_rows, dz_partials.shape[1]), dtype=torch.float32, device=dev)
                 job = (dz_partials, dz)
+            chain_bwd, max_nodes = ctx.chain_bwd
             last = 1 if ctx.fuse_step else 0                                    # the fused launch does step 1 -> 0
-            for i in range(steps - 1, last, -1):                                # dX[i-1] += A^T dX[i]
+            for i in range(steps - 1, steps - 1 if chain_bwd else last, -1):    # dX[i-1] += A^T dX[i]
                 st.spmm(dx[i], dx[i - 1], transpose=True, accumulate=True,
                         reduce_job=job if MERGED_LAUNCHES else None)
                 if MERGED_LAUNCHES:
@@ -295,16 +325,24 @@ class _RWKernelLayer(torch.autograd.Function):
             if ctx.fuse_step:
                 f = feats.shape[1]
                 csr_t = st.csr_t
-                blocks = plan["spb_blocks"]
+                blocks = st.n_graphs if chain_bwd else plan["spb_blocks"]
                 partials = torch.empty((blocks, d * f + d), dtype=torch.float32, device=dev)
                 d_inp = torch.empty_like(feats) if ctx.needs_input_grad[0] else None
                 red_in, red_out = job if job is not None else (None, None)
-                _lib.check(lib.rwk_spmm_project_backward(
-                    dx[0].data_ptr(), dx[1].data_ptr(), x0.data_ptr(), feats.data_ptr(), w_c.data_ptr(), n, f,
-                    csr_t.crow.data_ptr(), _lib.ptr(csr_t.col), _lib.ptr(csr_t.col16),
-                    None if (csr_t.col16 is not None and csr_t.unit_values) else _lib.ptr(csr_t.val),
-                    partials.data_ptr(), _lib.ptr(d_inp), _lib.ptr(red_in), red_in.shape[0] if job else 0,
-                    red_in.shape[1] if job else 0, _lib.ptr(red_out), stream), "rwk_spmm_project_backward")
+                if chain_bwd:       # the whole transposed chain and the projection's backward, per graph in LDS
+                    _lib.check(lib.rwk_graph_chain_backward(
+                        dx.data_ptr(), x0.data_ptr(), feats.data_ptr(), w_c.data_ptr(), n, f, csr_t.crow.data_ptr(),
+                        _lib.ptr(csr_t.col), None if csr_t.unit_values else _lib.ptr(csr_t.val),
+                        st.seg_ptr.data_ptr(), st.n_graphs, max_nodes, steps, partials.data_ptr(), _lib.ptr(d_inp),
+                        _lib.ptr(red_in), red_in.shape[0] if job else 0, red_in.shape[1] if job else 0,
+                        _lib.ptr(red_out), stream), "rwk_graph_chain_backward")
+                else:
+                    _lib.check(lib.rwk_spmm_project_backward(
+                        dx[0].data_ptr(), dx[1].data_ptr(), x0.data_ptr(), feats.data_ptr(), w_c.data_ptr(), n, f,
+                        csr_t.crow.data_ptr(), _lib.ptr(csr_t.col), _lib.ptr(csr_t.col16),
+                        None if (csr_t.col16 is not None and csr_t.unit_values) else _lib.ptr(csr_t.val),
+                        partials.data_ptr(), _lib.ptr(d_inp), _lib.ptr(red_in), red_in.shape[0] if job else 0,
+                        red_in.shape[1] if job else 0, _lib.ptr(red_out), stream), "rwk_spmm_project_backward")
                 wb = torch.empty(d * f + d, dtype=torch.float32, device=dev)
                 tail = ctx.handoff.get("tail") if ctx.handoff is not None else None
                 head = ctx.handoff.pop("head_grads", None) if tail is not None else None

@@ -581,6 +581,34 @@ int rwk_x_chain_hidden_forward(const float *features, const float *weight, const
                                const float *adj_hidden, const float *features_hidden, int64_t h, int64_t s, float *ah,
                                float *z, uint64_t *rng_state, uint64_t *rng_used, rwk_stream_t stream);
 
+/* The same chain for LARGE graphs of a block-diagonal batch (thousands of nodes, power-law hubs; rwgnn2/model.py:43,55
+ * at hidden_dim 4, at most 16 input features, sorted graph ids): one workgroup of up to 1024 threads per graph with
+ * the graph in LDS - 16 bytes per node for the current rows, the row pointers, and the columns as 16-bit node numbers
+ * within the graph (entries beyond the LDS share are read from memory).  Rows of at most 16 stored entries are
+ * summed by their own thread in stored order (same bits as the SpMM launches), rows of at most 128 by 16 lanes, longer
+ * ones by a wavefront (lane j adds entries j, j + lanes, ... in order, lane sums in a fixed butterfly).
+ * rwk_graph_chain_forward_lds: LDS bytes, 0 = unsupported (graphs of more than 4096 nodes). */
+int64_t rwk_graph_chain_forward_lds(int64_t f, int64_t max_nodes, int64_t s);
+int rwk_graph_chain_forward(const float *features, const float *weight, const float *bias, int64_t n, int64_t f,
+                            const int32_t *crow, const int32_t *col, const float *val, const int32_t *seg_ptr,
+                            int64_t n_graphs, int64_t max_nodes, int64_t max_step, float *xs, const float *adj_hidden,
+                            const float *features_hidden, int64_t h, int64_t s, float *ah, float *z,
+                            uint64_t *rng_state, uint64_t *rng_used, rwk_stream_t stream);
+
+/* Its backward (autograd of rwgnn2/model.py:55 and :43): dX_{i-1} += A^T dX_i for i = max_step-1 .. 1 with the
+ * graph's gradient rows in LDS, then on the finished dX_0 the projection's backward, one partial row
+ * [dW (4, f) | db (4)] per graph in partials (n_graphs, 4 f + 4) (summed by rwk_hidden_backward_reduce and its
+ * variants, or rwk_reduce_rows), d_features (n, f) when not NULL.  dx (max_step, n, 4) holds every step's own share
+ * (rwk_fused_backward*); it is only read.  crow_t / col_t / val_t: CSR of A^T (val_t NULL: every value is 1).
+ * Replaces max_step - 2 accumulating SpMM launches and rwk_spmm_project_backward.  red_in (may be NULL): the first
+ * level of an independent row reduction rides in trailing workgroups, as in rwk_spmm_project_backward. */
+int64_t rwk_graph_chain_backward_lds(int64_t f, int64_t max_nodes);
+int rwk_graph_chain_backward(const float *dx, const float *x0, const float *features, const float *weight, int64_t n,
+                             int64_t f, const int32_t *crow_t, const int32_t *col_t, const float *val_t,
+                             const int32_t *seg_ptr, int64_t n_graphs, int64_t max_nodes, int64_t max_step,
+                             float *partials, float *d_features, const float *red_in, int64_t red_p, int64_t red_v,
+                             float *red_out32, rwk_stream_t stream);
+
 /* rwk_reduce_rows for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same kernels, same order of
  * additions, same bits as rwk_reduce_rows; the 32 x v level-1 sums live in a device array of the library itself

@@ -119,6 +119,37 @@ def test_backward_full_size_against_oracle_vjp(name, n_graphs, dev):
     assert torch.equal(f1, feats.grad)
 
 
+@pytest.mark.parametrize("name", ["powerlaw", "powerlaw256"])
+def test_graph_chain_equals_spmm_launches_full_size(name, dev):
+    """Graphs of thousands of nodes with hubs: the propagation chain and its backward per graph in LDS
+    (function.GRAPH_CHAIN, csrc/rwk_chain.hip) against the SpMM launches they replace, in training mode at full size.
+    Rows of more than 64 stored entries are summed in another fixed order, so the comparison is to rounding."""
+    import gnn_amd.function as fn
+    hp, b, m = build(name, dev, train=True)
+    adj, feats, gi, _ = b.to_torch(dev)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    dk = torch.randn(b.n_graphs, hp["max_step"] * hp["hidden_graphs"], generator=g).to(dev)
+    runs = []
+    min_graphs = fn.GRAPH_CHAIN_MIN_GRAPHS
+    try:
+        fn.GRAPH_CHAIN_MIN_GRAPHS = 1          # (by default only batches that give every CU a graph take the chain)
+        for chain in (True, False):
+            fn.GRAPH_CHAIN = chain
+            m.seed_dropout(99)
+            m.zero_grad(set_to_none=True)
+            k = m.rw_features(adj, feats, gi)
+            k.backward(dk)
+            runs.append([k.detach().clone()] + [p.grad.clone() for p in (m.adj_hidden, m.features_hidden, m.fc.weight,
+                                                                      m.fc.bias)])
+    finally:
+        fn.GRAPH_CHAIN = True
+        fn.GRAPH_CHAIN_MIN_GRAPHS = min_graphs
+    floor = 6e-8 * np.sqrt(b.n_nodes) * 4 * float(dk.abs().max()) * float(np.abs(b.features).max())
+    for a, c in zip(*runs):
+        a64, c64 = a.double().cpu().numpy(), c.double().cpu().numpy()
+        assert np.abs(a64 - c64).max() <= 2e-6 * np.abs(c64).max() + floor
+
+
 def test_graph_permutation_invariance_full_size(dev):
     """Row g of K depends on graph g alone: the batch with its graphs in reverse order gives the same rows."""
     from gnn_amd.synth import Batch
@@ -155,6 +186,7 @@ def test_merged_launches_equal_separate_launches_full_size(name, dev):
     runs = []
     try:
         fn.FUSED_STEP_LAUNCHES = False
+        fn.GRAPH_CHAIN = False                 # (the per-graph chain sums hub rows in its own order: test_gpu_chain.py)
         for merged in (True, False):
             fn.MERGED_LAUNCHES = merged
             m.zero_grad(set_to_none=True)
@@ -165,6 +197,7 @@ def test_merged_launches_equal_separate_launches_full_size(name, dev):
     finally:
         fn.MERGED_LAUNCHES = True
         fn.FUSED_STEP_LAUNCHES = True
+        fn.GRAPH_CHAIN = True
     for a, c in zip(*runs):
         assert torch.equal(a, c)
 
@@ -182,6 +215,7 @@ def test_fused_step_launches_equal_separate_launches_full_size(name, dev):
     dk = torch.randn(b.n_graphs, hp["max_step"] * hp["hidden_graphs"], generator=g).to(dev)
     runs = []
     try:
+        fn.GRAPH_CHAIN = False                 # (see above)
         for fused in (True, False):
             fn.FUSED_STEP_LAUNCHES = fused
             m.zero_grad(set_to_none=True)
@@ -191,6 +225,7 @@ def test_fused_step_launches_equal_separate_launches_full_size(name, dev):
                                                                       m.fc.bias)])
     finally:
         fn.FUSED_STEP_LAUNCHES = True
+        fn.GRAPH_CHAIN = True
     for a, c in zip(runs[0][:3], runs[1][:3]):
         assert torch.equal(a, c)
     for a, c in zip(runs[0][3:], runs[1][3:]):           # sums of 3e5 signed terms in two different fixed orders
