@@ -69,8 +69,11 @@ def parse_args():
                          "the FETCH_SIZE / WRITE_SIZE counter passes are calibrated on")
     ap.add_argument("--only", default="", help="with --kernels-only: comma-separated kernel classes to launch")
     ap.add_argument("--capture-allreduce", action="store_true",
-                    help="--gpus N > 1: try to capture the gradient all-reduce inside the step graph (falls back to "
-                         "two graphs around an eager collective if the capture is refused); also RWK_CAPTURE_ALLREDUCE=1")
+                    help="(the default on RCCL; kept for older command lines) capture the gradient all-reduce inside "
+                         "the step graph")
+    ap.add_argument("--no-capture-allreduce", action="store_true",
+                    help="--gpus N > 1: graph of forward + backward, eager all-reduce, Adam launch (the fall-back shape); "
+                         "also RWK_CAPTURE_ALLREDUCE=0")
     ap.add_argument("--dp-shape", type=int, default=0,
                     help="one GPU only: time the step in the shape a rank of an N-rank run executes (two graphs and "
                          "the collective's slot between them, no process group) to see what the shape itself costs")
@@ -578,7 +581,12 @@ def main():
         raise SystemExit("%s is a batch of one graph: BatchNorm1d cannot train on it (model.py:68 raises in the "
                          "reference too); run it with --kernels-only" % args.config)
     shape_world = args.dp_shape if (world == 1 and args.dp_shape > 1) else world
-    capture_collective = args.capture_allreduce or os.environ.get("RWK_CAPTURE_ALLREDUCE", "0") == "1"
+    # RCCL runs capture the gradient all-reduce inside the step's graph (one replay per step, several steps per
+    # replay, nothing on the host in between: 0.099 against 0.110 ms per step in the one-rank rehearsal on RCCL); a
+    # capture the runtime refuses, or one whose replay leaves different gradients on the ranks, falls back to
+    # graph + eager all-reduce + Adam launch.  --no-capture-allreduce / RWK_CAPTURE_ALLREDUCE=0: that shape at once.
+    capture_collective = (backend == "nccl" and not args.no_capture_allreduce
+                          and os.environ.get("RWK_CAPTURE_ALLREDUCE", "1") != "0")
     launch = args.mode
     run_steps = None
     stream_bench = None
@@ -614,7 +622,8 @@ def main():
                      capture_collective=capture_collective and dist_on)
         if args.mode == "graph":
             try:
-                spg = args.steps_per_graph if (shape_world == 1 and args.steps_per_graph > 1) else 1
+                multi_ok = shape_world == 1 or (capture_collective and dist_on)
+                spg = args.steps_per_graph if (multi_ok and args.steps_per_graph > 1) else 1
                 tr.capture(steps_per_graph=spg)
                 step = tr.step_graph
                 if tr.multi_k > 1:

@@ -215,6 +215,10 @@ class Trainer:
         self.loss = None
         if self.world > 1 and self.capture_collective and not self.sync_before_all_reduce:
             if self._capture_single_graph():
+                # with the collective inside the graph nothing of a step happens on the host: several steps per replay,
+                # as with a single process
+                if steps_per_graph > 1:
+                    self._capture_multi(steps_per_graph, collective=True)
                 return
         self.collective_captured = False
         self.g_fb = torch.cuda.CUDAGraph()
@@ -234,18 +238,25 @@ class Trainer:
                 with torch.cuda.graph(self.g_opt, capture_error_mode=self.capture_error_mode):
                     self._opt_step()
         elif steps_per_graph > 1:
-            g_multi, losses = torch.cuda.CUDAGraph(), []
-            try:
-                with torch.cuda.graph(g_multi, capture_error_mode=self.capture_error_mode):
-                    for _ in range(steps_per_graph):
-                        self.fwd_bwd()
-                        self._opt_step()
-                        losses.append(self.loss.detach())
-                self.g_multi, self.losses, self.multi_k = g_multi, losses, int(steps_per_graph)
-            except Exception as exc:      # the single-step graph stays usable
-                torch.cuda.synchronize()
-                self.capture_note = "multi-step capture refused (%s: %s)" % (type(exc).__name__, str(exc)[:200])
-            self.loss = self._single_loss  # step_graph() leaves its loss here; run_steps() points it at the last one
+            self._capture_multi(steps_per_graph)
+
+    def _capture_multi(self, steps_per_graph: int, collective: bool = False):
+        """A second graph of ``steps_per_graph`` consecutive steps (``collective``: each with its all-reduce)."""
+        g_multi, losses = torch.cuda.CUDAGraph(), []
+        try:
+            with torch.cuda.graph(g_multi, capture_error_mode=self.capture_error_mode):
+                for _ in range(steps_per_graph):
+                    self.fwd_bwd()
+                    if collective:
+                        self.bucket.all_reduce()
+                    self._opt_step()
+                    losses.append(self.loss.detach())
+            self.g_multi, self.losses, self.multi_k = g_multi, losses, int(steps_per_graph)
+        except Exception as exc:      # the single-step graph stays usable
+            torch.cuda.synchronize()
+            note = "multi-step capture refused (%s: %s)" % (type(exc).__name__, str(exc)[:200])
+            self.capture_note = (self.capture_note + "; " if self.capture_note else "") + note
+        self.loss = self._single_loss  # step_graph() leaves its loss here; run_steps() points it at the last one
 
     def _capture_single_graph(self) -> bool:
         """forward+backward, all-reduce and update in one graph.  Returns False (with everything as it was before,
@@ -277,6 +288,7 @@ class Trainer:
             self.loss = None
             return False
         self.g_fb, self.g_opt = g, None
+        self._single_loss = self.loss = self.loss.detach()   # same storage, without the captured autograd graph
         self.collective_captured = True
         self.capture_note = "all-reduce captured inside the step graph"
         return True

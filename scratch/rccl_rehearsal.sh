@@ -6,9 +6,9 @@
 tag=$1
 out=gpurun_out/$tag; mkdir -p $out
 export RWK_REHEARSE_RCCL=1
-timeout -k 10 200 python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-kernel-timing --dp-shape 2 > $out/rccl1_two_graphs.json 2> $out/rccl1_two_graphs.err || { tail -20 $out/rccl1_two_graphs.err; exit 1; }
+timeout -k 10 200 python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-kernel-timing --dp-shape 2 --no-capture-allreduce > $out/rccl1_two_graphs.json 2> $out/rccl1_two_graphs.err || { tail -20 $out/rccl1_two_graphs.err; exit 1; }
 tail -c 600 $out/rccl1_two_graphs.json; echo
-timeout -k 10 200 python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-kernel-timing --dp-shape 2 --capture-allreduce > $out/rccl1_captured.json 2> $out/rccl1_captured.err || { tail -20 $out/rccl1_captured.err; exit 1; }
+timeout -k 10 200 python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-kernel-timing --dp-shape 2 > $out/rccl1_captured.json 2> $out/rccl1_captured.err || { tail -20 $out/rccl1_captured.err; exit 1; }
 tail -c 600 $out/rccl1_captured.json; echo
 timeout -k 10 200 python3 bench.py --steps 62 --warmup 8 --no-cpu-baseline --no-kernel-timing --dp-shape 2 --config stream_h64 --stream > $out/rccl1_stream.json 2> $out/rccl1_stream.err || { tail -20 $out/rccl1_stream.err; exit 1; }
 tail -c 600 $out/rccl1_stream.json; echo

@@ -1,6 +1,6 @@
 """One rank of the two-process data-parallel check on the HIP kernels (started by tests/conftest.py through
-``python -m torch.distributed.run --nproc-per-node 2``; both ranks share GPU 0, the gradient all-reduce goes over
-gloo).  Each rank takes its ``gnn_amd.dp.shard_ranges`` share of ONE 128-graph batch.
+``python -m torch.distributed.run --nproc-per-node 2``, before the test process touches the GPU; the ranks import what
+they need and then wait for the test's go-ahead; both ranks share GPU 0, the gradient all-reduce goes over gloo).  Each rank takes its ``gnn_amd.dp.shard_ranges`` share of ONE 128-graph batch.
 
 1. Layer level (no batch-norm, no dropout): the summed per-shard gradients of ``sum(K * W)`` equal the gradient one
    process computes on the whole batch, to 1e-5 (K rows depend on their own graph only, so the sum is exact up to
@@ -24,6 +24,15 @@ def main(outdir):
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     result = {"rank": rank, "ok": False}
     try:
+        # Everything is imported; the GPU work waits until the test asks for it (the file "go"), so that the ranks do
+        # not share the device with whatever other tests the session is running meanwhile.
+        import time
+        t_end = time.time() + 1800
+        while not os.path.exists(os.path.join(outdir, "go")):
+            if time.time() > t_end:
+                result.update(ok=True, skipped="the test that starts the ranks never ran")
+                return result
+            time.sleep(0.05)
         if not torch.cuda.is_available():
             result.update(ok=True, skipped="no GPU")
             return result

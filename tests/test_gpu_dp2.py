@@ -1,7 +1,7 @@
 """Two real processes stepping the HIP kernels: each rank trains on its ``shard_ranges`` share of one batch, gradients
 all-reduced over gloo (both ranks share the one GPU of the box).  The ranks are started by ``tests/conftest.py`` when
-the collection ends - before this process makes its first GPU call - and run beside the other tests; this test waits
-for them and reads their verdicts (``tests/dp2_worker.py`` documents what each rank checks)."""
+the collection ends - before this process makes its first GPU call - import what they need and wait; this test gives
+them the go-ahead, waits for them and reads their verdicts (``tests/dp2_worker.py`` documents what each rank checks)."""
 import json
 import os
 
@@ -15,6 +15,9 @@ def test_two_ranks_on_the_hip_kernels_end_with_identical_parameters(request):
     if job is None:
         pytest.skip("no GPU (the two-rank job was not started)")
     proc, outdir = job
+    import torch
+    torch.cuda.synchronize()                    # this process leaves the device to the two ranks
+    open(os.path.join(outdir, "go"), "w").close()
     try:
         rc = proc.wait(timeout=300)
     except Exception:
