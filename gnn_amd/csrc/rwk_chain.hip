@@ -18,9 +18,10 @@
 //   <= 16   the row's own thread, an fmaf chain in stored order (the order of the tile SpMM: same bits);
 //   <= 128  a group of 16 lanes: lane j adds entries j, j + 16, ... in order, the lane sums in a fixed butterfly;
 //   above   a wavefront, the same with 64 lanes.
-// The cooperative rows are listed once per launch, in thread order (a workgroup-wide prefix sum, not an atomic
-// counter), so which rows fit the lists - the others fall back to their own thread - does not depend on scheduling:
-// all sums in fixed orders, bitwise reproducible.
+// The cooperative rows are listed once per launch, in thread order, and the other rows are dealt to the threads sorted
+// by length class (graph_lists: a workgroup-wide prefix sum, not an atomic counter), so neither which rows fit the lists
+// - the others fall back to a thread - nor anything else depends on scheduling: all sums in fixed orders, bitwise
+// reproducible.
 #include "rwk_common.h"
 #include "rwk_hidden_body.h"
 #include "rwk_reduce_body.h"
@@ -51,8 +52,8 @@ struct ChainLayout {
     int max_nodes, cap_a, cap_b, cap_cols, extra_floats, threads;
     __host__ __device__ size_t bytes() const {
         return (size_t)max_nodes * 16 + (size_t)(cap_a + cap_b) * 16 + (size_t)(max_nodes + 1) * 4 +
-               (size_t)(threads / RWK_WAVE + 4) * 4 + (size_t)extra_floats * 4 + (size_t)(cap_a + cap_b) * 2 +
-               (size_t)cap_cols * 2;
+               (size_t)(4 * (threads / RWK_WAVE) + 4) * 4 + (size_t)extra_floats * 4 +
+               (size_t)(cap_a + cap_b + max_nodes) * 2 + (size_t)cap_cols * 2;
     }
 };
 
@@ -82,13 +83,15 @@ struct GraphView {
     float4 *x;                 // [max_nodes] rows of the current step
     float4 *stage;             // [cap_a + cap_b] results of the listed rows, until every read of x is done
     int *crow;                 // [max_nodes + 1] row pointers relative to the graph's first entry
-    int *misc;                 // [waves] wavefront totals of the prefix sum, then [waves .. waves+1] the list lengths
+    int *misc;                 // [4 * waves] wavefront totals of the prefix sum (seven 16-bit counters in two words)
     float *extra;
-    unsigned short *list_a, *list_b, *cols;
+    unsigned short *list_a, *list_b;
+    unsigned short *perm;      // [max_nodes] the rows summed by their own thread, sorted by length class
+    unsigned short *cols;
     int cap_a, cap_b, cap_cols;
     const int *gcol;
     const float *gval;
-    int p0, ng, eb, n_a, n_b;
+    int p0, ng, eb, n_a, n_b, n_own;
 };
 
 template <int THREADS>
@@ -98,13 +101,14 @@ __device__ inline GraphView graph_view(float *lds, const ChainLayout &l, const i
     v.stage = v.x + l.max_nodes;
     v.crow = reinterpret_cast<int *>(v.stage + l.cap_a + l.cap_b);
     v.misc = v.crow + l.max_nodes + 1;
-    v.extra = reinterpret_cast<float *>(v.misc + THREADS / RWK_WAVE + 4);
+    v.extra = reinterpret_cast<float *>(v.misc + 4 * (THREADS / RWK_WAVE) + 4);
     v.list_a = reinterpret_cast<unsigned short *>(v.extra + l.extra_floats);
     v.list_b = v.list_a + l.cap_a;
-    v.cols = v.list_b + l.cap_b;
+    v.perm = v.list_b + l.cap_b;
+    v.cols = v.perm + l.max_nodes;
     v.cap_a = l.cap_a; v.cap_b = l.cap_b; v.cap_cols = l.cap_cols;
     v.gcol = gcol; v.gval = gval;
-    v.p0 = v.ng = v.eb = v.n_a = v.n_b = 0;
+    v.p0 = v.ng = v.eb = v.n_a = v.n_b = v.n_own = 0;
     return v;
 }
 
@@ -193,79 +197,123 @@ __device__ inline float4 lanes_sum(float4 p) {
     return p;
 }
 
-// Lists of the cooperative rows, in thread order.  Returns the mask of this thread's rows (bit r: row tid + r *
-// THREADS) that the thread sums itself: the short ones and those the lists had no room for.  Barriers inside.
+// Who sums which row.  Rows of more than kShortRow entries go to the two lists of cooperative rows (in thread order; a
+// row the lists have no room for stays with a thread).  All other rows are dealt to the threads SORTED by the number of
+// four-entry batches their sum takes (longest first): slot q of the order is summed by thread q % THREADS in its round
+// q / THREADS, so the 64 rows a wavefront sums in one round are of one length class - in natural order most lanes of
+// a wavefront idle while the longest of its 64 rows finishes (power-law graphs: most rows have one or two entries;
+// a step of a 3000-node graph took 6 us that way).  Positions come from one workgroup-wide prefix sum over seven
+// counters (no atomic counter: the order does not depend on scheduling).  Barriers inside.
 template <int THREADS>
-__device__ inline unsigned graph_lists(GraphView &v) {
+__device__ inline void graph_lists(GraphView &v) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int kWaves = THREADS / RWK_WAVE;
-    int cls[kRpt];
-    int cnt = 0;                                   // listed-class rows of this thread: A in the low half, B in the high
+    // counters, 16 bits each: lo = own rows of 4, 3, 2, 1 batches; hi = own rows without entries, list A, list B
+    int key[kRpt];
+    unsigned long long lo = 0, hi = 0;
 #pragma unroll
     for (int r = 0; r < kRpt; ++r) {
         const int local = tid + r * THREADS;
-        cls[r] = -1;
+        key[r] = -1;
         if (local < v.ng) {
             const int len = v.crow[local + 1] - v.crow[local];
-            cls[r] = len <= kShortRow ? 0 : (len <= kGroupRow ? 1 : 2);
-            if (cls[r] == 1) cnt += 1;
-            if (cls[r] == 2) cnt += 1 << 16;
+            key[r] = len > kGroupRow ? 6 : (len > kShortRow ? 5 : 4 - ((len + 3) >> 2));
+            if (key[r] < 4) lo += 1ull << (16 * key[r]);
+            else hi += 1ull << (16 * (key[r] - 4));
         }
     }
-    int incl = cnt;
+    unsigned long long ilo = lo, ihi = hi;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
+        const unsigned long long tl = __shfl_up(ilo, off, 64), th = __shfl_up(ihi, off, 64);
+        if (lane >= off) { ilo += tl; ihi += th; }
     }
-    if (lane == 63) v.misc[wave] = incl;
+    if (lane == 63) {
+        v.misc[4 * wave + 0] = (int)(unsigned)ilo;
+        v.misc[4 * wave + 1] = (int)(unsigned)(ilo >> 32);
+        v.misc[4 * wave + 2] = (int)(unsigned)ihi;
+        v.misc[4 * wave + 3] = (int)(unsigned)(ihi >> 32);
+    }
     __syncthreads();
-    int before = incl - cnt;
-    int total = 0;
+    unsigned long long blo = ilo - lo, bhi = ihi - hi, tlo = 0, thi = 0;
 #pragma unroll
     for (int q = 0; q < kWaves; ++q) {
-        const int t = v.misc[q];
-        if (q < wave) before += t;
-        total += t;
+        const unsigned long long wl = (unsigned)v.misc[4 * q] | ((unsigned long long)(unsigned)v.misc[4 * q + 1] << 32);
+        const unsigned long long wh = (unsigned)v.misc[4 * q + 2] | ((unsigned long long)(unsigned)v.misc[4 * q + 3] << 32);
+        if (q < wave) { blo += wl; bhi += wh; }
+        tlo += wl; thi += wh;
     }
-    int ia = before & 0xFFFF, ib = before >> 16;
-    unsigned mine = 0;
+    int before[7], total[7];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        before[k] = (int)((blo >> (16 * k)) & 0xFFFF);
+        total[k] = (int)((tlo >> (16 * k)) & 0xFFFF);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        before[4 + k] = (int)((bhi >> (16 * k)) & 0xFFFF);
+        total[4 + k] = (int)((thi >> (16 * k)) & 0xFFFF);
+    }
+    const int over_a = total[5] > v.cap_a ? total[5] - v.cap_a : 0;
+    const int over_b = total[6] > v.cap_b ? total[6] - v.cap_b : 0;
+    int base[5];
+    base[0] = over_a + over_b;                     // the rows the lists had no room for come first: they are the longest
+#pragma unroll
+    for (int k = 1; k < 5; ++k) base[k] = base[k - 1] + total[k - 1];
 #pragma unroll
     for (int r = 0; r < kRpt; ++r) {
         const int local = tid + r * THREADS;
-        if (cls[r] == 0) mine |= 1u << r;
-        if (cls[r] == 1) {
-            if (ia < v.cap_a) v.list_a[ia] = (unsigned short)local; else mine |= 1u << r;
-            ++ia;
-        }
-        if (cls[r] == 2) {
-            if (ib < v.cap_b) v.list_b[ib] = (unsigned short)local; else mine |= 1u << r;
-            ++ib;
+        const int k = key[r];
+        if (k < 0) continue;
+        int at = 0;
+#pragma unroll
+        for (int q = 0; q < 7; ++q)
+            if (q == k) at = before[q]++;
+        if (k < 5) {
+            int b0 = 0;
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+                if (q == k) b0 = base[q];
+            v.perm[b0 + at] = (unsigned short)local;
+        } else if (k == 5) {
+            if (at < v.cap_a) v.list_a[at] = (unsigned short)local;
+            else v.perm[at - v.cap_a] = (unsigned short)local;
+        } else {
+            if (at < v.cap_b) v.list_b[at] = (unsigned short)local;
+            else v.perm[over_a + at - v.cap_b] = (unsigned short)local;
         }
     }
-    const int ta = total & 0xFFFF, tb = total >> 16;
-    v.n_a = ta < v.cap_a ? ta : v.cap_a;
-    v.n_b = tb < v.cap_b ? tb : v.cap_b;
+    v.n_a = total[5] - over_a;
+    v.n_b = total[6] - over_b;
+    v.n_own = base[4] + total[4];
     __syncthreads();
-    return mine;
 }
 
-// One product step on the view: res[r] = (A x)[row r of this thread] (+ own(row)), listed rows into the staging block.
+// the rows this thread sums itself (-1: none), constant over the steps of a launch
+template <int THREADS>
+__device__ inline void graph_own_rows(const GraphView &v, int (&loc)[kRpt]) {
+#pragma unroll
+    for (int r = 0; r < kRpt; ++r) {
+        const int slot = threadIdx.x + r * THREADS;
+        loc[r] = slot < v.n_own ? (int)v.perm[slot] : -1;
+    }
+}
+
+// One product step on the view: res[r] = (A x)[loc[r]] (+ own(row)), listed rows into the staging block.
 // OWN: float4 operator()(int local) - the addend of a row (the step's own gradient share in the backward chain).
 template <int THREADS, bool ADD, class OWN>
-__device__ inline void graph_step(const GraphView &v, unsigned mine, float4 (&res)[kRpt], const OWN &own) {
+__device__ inline void graph_step(const GraphView &v, const int (&loc)[kRpt], float4 (&res)[kRpt], const OWN &own) {
     const int tid = threadIdx.x;
     float4 o[kRpt];
 #pragma unroll
     for (int r = 0; r < kRpt; ++r) {              // requested together, used after the row's sum
         o[r] = f4_zero();
-        if (ADD && ((mine >> r) & 1u)) o[r] = own(tid + r * THREADS);
+        if (ADD && loc[r] >= 0) o[r] = own(loc[r]);
     }
 #pragma unroll
     for (int r = 0; r < kRpt; ++r) {
-        if (!((mine >> r) & 1u)) continue;
-        const int local = tid + r * THREADS;
-        const int e0 = v.crow[local], e1 = v.crow[local + 1];
+        if (loc[r] < 0) continue;
+        const int e0 = v.crow[loc[r]], e1 = v.crow[loc[r] + 1];
         float4 acc = entries_sum(v, e0, e1, 1);
         if (ADD) f4_add(acc, o[r]);               // as the accumulating SpMM adds it: (sum over the row) + y
         res[r] = acc;
@@ -299,15 +347,15 @@ __device__ inline void graph_step(const GraphView &v, unsigned mine, float4 (&re
 // every read of x is done: the step's results become the rows.  STORE: void operator()(int local, float4) - what else
 // happens to a finished row (the forward chain writes it to memory).
 template <int THREADS, class STORE>
-__device__ inline void graph_commit(const GraphView &v, unsigned mine, const float4 (&res)[kRpt], const STORE &store) {
+__device__ inline void graph_commit(const GraphView &v, const int (&loc)[kRpt], const float4 (&res)[kRpt],
+                                    const STORE &store) {
     const int tid = threadIdx.x;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < kRpt; ++r) {
-        if (!((mine >> r) & 1u)) continue;
-        const int local = tid + r * THREADS;
-        v.x[local] = res[r];
-        store(local, res[r]);
+        if (loc[r] < 0) continue;
+        v.x[loc[r]] = res[r];
+        store(loc[r], res[r]);
     }
     for (int k = tid; k < v.n_a; k += THREADS) {
         const int local = v.list_a[k];
@@ -400,11 +448,13 @@ __global__ void __launch_bounds__(THREADS) chain_forward_kernel(const ChainForwa
         x0g[node] = t;
     }
     if (a.steps <= 1) return;
-    const unsigned mine = graph_lists<THREADS>(v);             // (its barriers also publish the projected rows)
+    graph_lists<THREADS>(v);                                   // (its barriers also publish the projected rows)
+    int loc[kRpt];
+    graph_own_rows<THREADS>(v, loc);
     for (int i = 1; i < a.steps; ++i) {
         float4 res[kRpt];
-        graph_step<THREADS, false>(v, mine, res, NoOwn{});
-        graph_commit<THREADS>(v, mine, res, RowStore{reinterpret_cast<float4 *>(a.xs) + (size_t)i * a.n, p0});
+        graph_step<THREADS, false>(v, loc, res, NoOwn{});
+        graph_commit<THREADS>(v, loc, res, RowStore{reinterpret_cast<float4 *>(a.xs) + (size_t)i * a.n, p0});
     }
 }
 
@@ -472,11 +522,13 @@ __global__ void __launch_bounds__(THREADS) chain_backward_kernel(const ChainBack
         }
     }
     __syncthreads();
-    const unsigned mine = graph_lists<THREADS>(v);
+    graph_lists<THREADS>(v);
+    int loc[kRpt];
+    graph_own_rows<THREADS>(v, loc);
     for (int i = a.steps - 1; i >= 1; --i) {
         float4 res[kRpt];
-        graph_step<THREADS, true>(v, mine, res, OwnShare{dxg + (size_t)(i - 1) * a.n + p0});
-        graph_commit<THREADS>(v, mine, res, NoStore{});
+        graph_step<THREADS, true>(v, loc, res, OwnShare{dxg + (size_t)(i - 1) * a.n + p0});
+        graph_commit<THREADS>(v, loc, res, NoStore{});
     }
     // v.x: the complete dX_0 of this graph.  Projection backward, a thread's rows in row order.
     float acc_w[4][FP], acc_b[4];

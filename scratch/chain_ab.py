@@ -11,6 +11,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "powerlaw256"
 dev = torch.device("cuda:0")
 hp = dict(CONFIGS[name]["hp"])
 batch_t = config_batch(name, 1).to_torch(dev)
+fn.GRAPH_CHAIN_MIN_GRAPHS = 1          # the comparison itself decides where the chain pays
 for chain in (True, False, True, False):
     fn.GRAPH_CHAIN = chain
     torch.manual_seed(0)
