@@ -197,8 +197,8 @@ struct ProjectGradOp {
 // value are read coalesced, each entry's x row is gathered by VEC lanes (every gather of a pass is in
 // flight at once) and parked in LDS.  Phase 2 walks it row-parallel: the row's lanes add its entries
 // from LDS in stored order (an fmaf chain, as a sequential CSR loop would).  Rows with more than
-// kLongRow entries in the tile (power-law hubs) are summed by the whole workgroup instead, in a fixed
-// tree order.  y is written coalesced, one 16-byte chunk per lane.
+// kLongRow entries in the tile (power-law hubs) are summed by a wavefront each instead, in a fixed
+// order (strided lane sums, then a butterfly).  y is written coalesced, one 16-byte chunk per lane.
 constexpr int kTileBytes = 16 * 1024;
 constexpr int kLongRow = 64;
 
@@ -297,35 +297,39 @@ __device__ inline void spmm_tile_body(int bid, int nblocks, const int32_t *__res
         }
         __syncthreads();
         const int n_long = s_nlong;
-        for (int k = 0; k < n_long; ++k) {               // uniform over the workgroup
-            const int rs = s_long[k];
-            const int lo_k = s_crow[rs] > cb ? s_crow[rs] : cb;
-            const int hi_k = s_crow[rs + 1] < ce ? s_crow[rs + 1] : ce;
-            float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int e = lo_k + slot; e < hi_k; e += RPW) {
-                const float w = UNIT ? 1.f : s_val[e - cb];
-                const float4 t = s_x[(e - cb) * VEC + sub];
-                part.x = fmaf(w, t.x, part.x);
-                part.y = fmaf(w, t.y, part.y);
-                part.z = fmaf(w, t.z, part.z);
-                part.w = fmaf(w, t.w, part.w);
-            }
-            s_red[tid] = part;
-            __syncthreads();
-            for (int off = RPW / 2; off >= 1; off >>= 1) {
-                if (slot < off) {
-                    const float4 o = s_red[(slot + off) * VEC + sub];
-                    float4 m = s_red[tid];
-                    m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
-                    s_red[tid] = m;
+        if (n_long > 0) {                                // uniform over the workgroup
+            // a wavefront per long row: lane (el, sub) adds entries el, el + 64/VEC, ... of the row's part in this
+            // tile, the lane sums of a chunk are added in a fixed butterfly (no barrier per row: the whole workgroup
+            // with a tree through LDS took nine of them per row, 1 us each on power-law batches)
+            constexpr int EL = RWK_WAVE / VEC;
+            const int wave = tid >> 6, el = (tid & 63) / VEC;
+            for (int k = wave; k < n_long; k += kBlock / RWK_WAVE) {
+                const int rs = s_long[k];
+                const int lo_k = s_crow[rs] > cb ? s_crow[rs] : cb;
+                const int hi_k = s_crow[rs + 1] < ce ? s_crow[rs + 1] : ce;
+                float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int e = lo_k + el; e < hi_k; e += EL) {
+                    const float w = UNIT ? 1.f : s_val[e - cb];
+                    const float4 t = s_x[(e - cb) * VEC + sub];
+                    part.x = fmaf(w, t.x, part.x);
+                    part.y = fmaf(w, t.y, part.y);
+                    part.z = fmaf(w, t.z, part.z);
+                    part.w = fmaf(w, t.w, part.w);
                 }
-                __syncthreads();
+#pragma unroll
+                for (int off = VEC; off < RWK_WAVE; off <<= 1) {
+                    part.x += __shfl_xor(part.x, off, 64);
+                    part.y += __shfl_xor(part.y, off, 64);
+                    part.z += __shfl_xor(part.z, off, 64);
+                    part.w += __shfl_xor(part.w, off, 64);
+                }
+                if (el == 0) s_red[rs * VEC + sub] = part;
             }
-            if (slot == rs) {
-                const float4 t = s_red[sub];
+            __syncthreads();
+            if (is_long) {
+                const float4 t = s_red[tid];
                 acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
             }
-            __syncthreads();
         }
         if (tid == 0) s_nlong = 0;
         __syncthreads();
