@@ -246,6 +246,11 @@ __device__ inline void spmm_tile_body(int bid, int nblocks, const int32_t *__res
     const int end = has_row ? s_crow[slot + 1] : 0;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    // columns (and values) of the next tile's first pass group, requested behind the current group's gathers: a
+    // workgroup with several tiles (hub rows) then waits one trip per further tile instead of two
+    int cn[GP];
+    float vn[GP];
+    bool have_next = false;
     for (int cb = e0; cb < e1; cb += ET) {
         const int ce = cb + ET < e1 ? cb + ET : e1;
         // phase 1, four entry passes at a time: unconditional loads at clamped indices, so that the four
@@ -255,16 +260,34 @@ __device__ inline void spmm_tile_body(int bid, int nblocks, const int32_t *__res
             if (cb + g * RPW >= ce) break;               // uniform
             int c[GP];
             float v[GP];
+            if (g == 0 && have_next) {
 #pragma unroll
-            for (int k = 0; k < GP; ++k) {
-                const int e = cb + slot + (g + k) * RPW;
-                const int ec = e < ce ? e : ce - 1;
-                c[k] = (int)col[ec] + col_base;
-                v[k] = UNIT ? 1.f : val[ec];
+                for (int k = 0; k < GP; ++k) { c[k] = cn[k]; v[k] = vn[k]; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < GP; ++k) {
+                    const int e = cb + slot + (g + k) * RPW;
+                    const int ec = e < ce ? e : ce - 1;
+                    c[k] = (int)col[ec] + col_base;
+                    v[k] = UNIT ? 1.f : val[ec];
+                }
             }
             float4 xv[GP];
 #pragma unroll
             for (int k = 0; k < GP; ++k) xv[k] = op.template fetch<ALIGNED>(c[k], sub);
+            const bool last_group = g + GP >= PASSES || cb + (g + GP) * RPW >= ce;
+            have_next = false;
+            if (last_group && ce < e1) {                  // uniform
+                const int nb = ce, ne = nb + ET < e1 ? nb + ET : e1;
+#pragma unroll
+                for (int k = 0; k < GP; ++k) {
+                    const int e = nb + slot + k * RPW;
+                    const int ec = e < ne ? e : ne - 1;
+                    cn[k] = (int)col[ec] + col_base;
+                    vn[k] = UNIT ? 1.f : val[ec];
+                }
+                have_next = true;
+            }
 #pragma unroll
             for (int k = 0; k < GP; ++k) {
                 const int e = cb + slot + (g + k) * RPW;
