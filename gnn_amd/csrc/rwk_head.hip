@@ -1057,7 +1057,42 @@ head_train_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
         HEAD_STAMP_AT(22);
         // this tile's share of the parameter sums.  Every element is sum_r A[r] * (B[r] * ga + be) over the tile's rows
         // (plain column sums take B = 1): four elements at a time, their 64 LDS reads in flight together, rows in order.
-        for (int e0 = tid; e0 < nv; e0 += 4 * kBlock) {
+        // d w1 (p x c of the nv elements) in register tiles of 2 rows x 4 columns of w1: the eight values of each of
+        // the two d(pre-activation) columns and of the four normalised-input columns are read once for eight
+        // elements (6 LDS reads per element instead of 16; this phase was 30-45 % of the kernel at 64 and 128
+        // columns).  Same products, added in the same (row) order: same bits as the element-wise form below.
+        const bool w1_tiled = (p & 1) == 0 && (c & 3) == 0;
+        if (w1_tiled) {
+            const int cq = c >> 2, n_tiles = (p >> 1) * cq;
+            const FastDiv by_cq(cq);
+            for (int q = tid; q < n_tiles; q += kBlock) {
+                const int j2 = by_cq.div(q), j0 = 2 * j2, c0 = 4 * (q - j2 * cq);
+                float dpv[2][kRows], yv[4][kRows];
+#pragma unroll
+                for (int r = 0; r < kRows; ++r) {
+                    dpv[0][r] = s_dp[r * ps + j0];
+                    dpv[1][r] = s_dp[r * ps + j0 + 1];
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) yv[cc][r] = s_xh[r * cs + c0 + cc];
+                }
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const float ga = s_ga[c0 + cc], be = s_be[c0 + cc];
+                    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < kRows; ++r) {
+                        const float y = fmaf(yv[cc][r], ga, be);
+                        a0 = fmaf(dpv[0][r], y, a0);
+                        a1 = fmaf(dpv[1][r], y, a1);
+                    }
+                    s_g[o_w1 + j0 * c + c0 + cc] += a0;
+                    s_g[o_w1 + (j0 + 1) * c + c0 + cc] += a1;
+                }
+            }
+        }
+        const int w1_skip = w1_tiled ? p * c : 0;            // the remaining elements, numbered without the d w1 block
+        const int nv_rest = nv - w1_skip;
+        for (int e0 = tid; e0 < nv_rest; e0 += 4 * kBlock) {
             // operands as offsets into the workgroup's LDS block (pointers chosen at run time among several arrays
             // would lose their address space and be read through the flat path)
             int oa[4], ob[4], sa[4], sb[4];
@@ -1066,8 +1101,9 @@ head_train_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
                       f_dp = (int)(s_dp - lds), f_xh = (int)(s_xh - lds), f_y = (int)(s_y - lds);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int e_raw = e0 + u * kBlock;
-                const int e = e_raw < nv ? e_raw : nv - 1;
+                const int i_raw = e0 + u * kBlock;
+                const int i_c = i_raw < nv_rest ? i_raw : nv_rest - 1;
+                const int e = i_c < o_w1 ? i_c : i_c + w1_skip;
                 ga4[u] = 1.f; be4[u] = 0.f; acc[u] = 0.f;
                 if (e < o_b2) {                               // d w2[q][j] = sum_r dl[r][q] h[r][j]
                     const int q = by_p.div(e), j = e - q * p;
@@ -1099,8 +1135,8 @@ head_train_kernel(const float *__restrict__ k, HeadDims dm, const float *__restr
             for (int u = 0; u < 4; ++u) {
 #pragma unroll
                 for (int r = 0; r < kRows; ++r) acc[u] = fmaf(av[u][r], fmaf(bv[u][r], ga4[u], be4[u]), acc[u]);
-                const int e = e0 + u * kBlock;
-                if (e < nv) s_g[e] += acc[u];
+                const int i = e0 + u * kBlock;
+                if (i < nv_rest) s_g[i < o_w1 ? i : i + w1_skip] += acc[u];
             }
         }
         __syncthreads();
