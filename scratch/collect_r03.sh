@@ -35,3 +35,11 @@ for k,v in d.items():
 for sc in weak strong; do RWK_DIST_BACKEND=gloo timeout -k 10 200 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --scaling $sc --steps 30 --warmup 5 --no-kernel-timing > $out/gloo2_$sc.json 2> $out/gloo2_$sc.err || { tail -5 $out/gloo2_$sc.err; exit 1; }; python3 -c "
 import json; d=json.loads(open('$out/gloo2_$sc.json').read().strip().splitlines()[-1]); print('gloo2 $sc', d['ms_per_step'], d['value'], d['scaling'])"; done
 echo done
+# what the later part of the round added: the per-graph chain against the SpMM launches, the one-rank RCCL rehearsal
+PYTHONPATH=. timeout -k 10 200 python3 scratch/chain_time.py > $out/chain_time.txt 2>&1; grep -v amdgpu $out/chain_time.txt
+PYTHONPATH=. timeout -k 10 200 python3 scratch/chain_ab.py powerlaw256 > $out/chain_ab_powerlaw256.txt 2>&1; grep "ms per" $out/chain_ab_powerlaw256.txt
+bash scratch/prof_cfg.sh powerlaw > $out/powerlaw_kernels.txt 2>&1; head -12 $out/powerlaw_kernels.txt
+bash scratch/rccl_rehearsal.sh $tag > $out/rccl_rehearsal.txt 2>&1 || { tail -5 $out/rccl_rehearsal.txt; exit 1; }
+for f in rccl1_two_graphs rccl1_captured rccl1_stream; do python3 -c "
+import json; d=json.loads(open('$out/$f.json').read().strip().splitlines()[-1]); print('$f', d['ms_per_step'], d['value'])"; done
+echo done2
