@@ -11,6 +11,8 @@ fresh masks.
 """
 from __future__ import annotations
 
+import os
+
 import contextlib
 import warnings
 
@@ -267,6 +269,9 @@ class Trainer:
             with torch.cuda.graph(g, capture_error_mode=self.capture_error_mode):
                 self.fwd_bwd()
                 self.bucket.all_reduce()
+                if os.environ.get("RWK_ABORT_CAPTURE_FOR_TEST") == "1":
+                    # rehearsal of the fall-back: a capture that fails AFTER the collective was recorded
+                    raise RuntimeError("capture aborted on purpose")
                 self._opt_step()
         except Exception as exc:                         # refused by the runtime or the collective library
             self.capture_note = "all-reduce capture refused (%s: %s)" % (type(exc).__name__, str(exc)[:200])
