@@ -247,7 +247,9 @@ __device__ inline void spmm_tile_body(int bid, int nblocks, const int32_t *__res
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // columns (and values) of the next tile's first pass group, requested behind the current group's gathers: a
-    // workgroup with several tiles (hub rows) then waits one trip per further tile instead of two
+    // workgroup with several tiles (hub rows) then waits one trip per further tile instead of two.  (In this form the
+    // compiler also keeps the four column loads of a group together and the four gathers behind them; in the plain
+    // loop it had peeled the first pass off as a dependent load pair of its own: 241 against 215 us on 19.7 M rows.)
     int cn[GP];
     float vn[GP];
     bool have_next = false;
