@@ -418,6 +418,52 @@ def test_spmm_compact_structure(dev):
     assert torch.equal(ya, yb)
 
 
+@pytest.mark.parametrize("weighted", [False, True])
+def test_spmm_tile_kernel_on_large_matrices(weighted, dev):
+    """The tile SpMM on 2.2 M rows (8600 and 17200 row blocks at one and two float4 chunks per row) of 0..7 entries,
+    one row block without any: same bits as the packed kernel's sequential sum per row, for y = A x, y += A x and the
+    transposed product; a sample of rows against float64."""
+    from gnn_amd import GraphStructure
+    rng = np.random.default_rng(23)
+    n = 2_200_000
+    deg = rng.integers(0, 8, size=n)
+    deg[1000:1300] = 0                                      # a whole row block without entries
+    rows = np.repeat(np.arange(n), deg)
+    off = rng.integers(-2000, 2001, size=rows.size)
+    cols = rows + off
+    cols = np.where((cols < 0) | (cols >= n), rows - off, cols)      # reflected at the ends: no hub columns
+    key = np.unique(rows.astype(np.int64) * n + cols)
+    rows, cols = key // n, key % n
+    vals = rng.uniform(0.5, 1.5, size=rows.size).astype(np.float32) if weighted else np.ones(rows.size, np.float32)
+    adj = torch.sparse_coo_tensor(torch.from_numpy(np.vstack([rows, cols])), torch.from_numpy(vals), (n, n)).to(dev)
+    st = GraphStructure.build(adj, torch.zeros(n, dtype=torch.int64, device=dev))
+    assert st.csr.col16 is not None and st.csr.unit_values == (not weighted)
+    assert max(st.csr.max_degree, st.csr_t.max_degree) <= 64      # (longer rows are summed in another order)
+    for d, n_used in ((4, n), (6, n)):
+        x = torch.from_numpy(rng.uniform(-1, 1, size=(n, d)).astype(np.float32)).to(dev)
+        for transpose in (False, True):
+            ya, yb = torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
+            st.spmm(x, ya, transpose=transpose, kernel="tile")
+            st.spmm(x, yb, transpose=transpose, kernel="packed")
+            assert torch.equal(ya, yb), (d, transpose)
+            y0 = torch.from_numpy(rng.uniform(-1, 1, size=(n, d)).astype(np.float32)).to(dev)
+            yc, yd = y0.clone(), y0.clone()
+            st.spmm(x, yc, transpose=transpose, accumulate=True, kernel="tile")
+            st.spmm(x, yd, transpose=transpose, accumulate=True, kernel="packed")
+            assert torch.equal(yc, yd), (d, transpose, "accumulate")
+            ye = torch.empty_like(x)
+            st.spmm(x, ye, transpose=transpose, kernel="tile")
+            assert torch.equal(ya, ye), "bitwise reproducible"
+        # float64 on the first and last 5000 rows
+        for lo, hi in ((0, 5000), (n - 5000, n)):
+            sel = (rows >= lo) & (rows < hi)
+            want = np.zeros((hi - lo, d))
+            np.add.at(want, rows[sel] - lo, vals[sel, None].astype(np.float64) * x.cpu().numpy()[cols[sel]].astype(np.float64))
+            y = torch.empty_like(x)
+            st.spmm(x, y, kernel="tile")
+            assert rel_err(y[lo:hi].cpu().numpy(), want) < TOL
+
+
 def test_error_behaviour(dev):
     """Inputs the reference rejects are rejected here too (model.py:60 raises on id gaps)."""
     from gnn_amd import GraphStructure
