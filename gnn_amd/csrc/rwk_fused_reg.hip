@@ -553,11 +553,19 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
                         dp_cur[i][0] = own_h ? dk * f : 0.f;
                     }
                 } else {
+                    // every lane loads (a lane without a hidden graph at its neighbour's address) and the unused values
+                    // are dropped afterwards: under a per-lane condition each of the LT * SK loads sat in a block of
+                    // its own with a wait behind it - ten trips to the L2 in a row at two steps and five hidden nodes
+                    const int lane_c = own_h ? lane_h : h - 1;
+                    float t[LT][SK];
 #pragma unroll
                     for (int i = 0; i < LT; ++i)
 #pragma unroll
-                        for (int q = 0; q < SK; ++q)
-                            dp_cur[i][q] = own_h ? d_k[((size_t)g * lh + i * h + lane_h) * SK + q] * f : 0.f;
+                        for (int q = 0; q < SK; ++q) t[i][q] = d_k[((size_t)g * lh + i * h + lane_c) * SK + q];
+#pragma unroll
+                    for (int i = 0; i < LT; ++i)
+#pragma unroll
+                        for (int q = 0; q < SK; ++q) dp_cur[i][q] = own_h ? t[i][q] * f : 0.f;
                 }
             }
             // no validity branch: a slot past the end of the stream has x = 0, so zx = t = 0 and every

@@ -187,22 +187,26 @@ kreduce_stats_kernel(const float *__restrict__ k_partials, const int *__restrict
         float acc[kKrRows] = {0.f, 0.f};
         bool more = true;
         while (more) {
-            float a[kKrRows][kKrSlots];
+            // A slot past the row's last one is loaded at a clamped index and enters the sum times 0.0f (a slot of the
+            // row times 1.0f: fmaf(a, 1, acc) is acc + a, the same bits).  With a select on the loaded value instead
+            // the compiler waited for most of the loads one by one (vmcnt(0) behind each, to reuse its register): a
+            // dozen trips to the L2 in a row where one was meant.
+            float a[kKrRows][kKrSlots], m[kKrRows][kKrSlots];
 #pragma unroll
             for (int q = 0; q < kKrRows; ++q) {
                 const float *src = k_partials + (size_t)rows[q] * c + col;
 #pragma unroll
                 for (int u = 0; u < kKrSlots; ++u) {
                     const int cs = cur[q] + u;
+                    m[q][u] = cs <= last[q] ? 1.f : 0.f;
                     a[q][u] = src[(size_t)(cs <= last[q] ? cs : last[q]) * c];
-                    if (cs > last[q]) a[q][u] = 0.f;                  // past the row's last slot: adds an exact zero
                 }
             }
             more = false;
 #pragma unroll
             for (int q = 0; q < kKrRows; ++q) {
 #pragma unroll
-                for (int u = 0; u < kKrSlots; ++u) acc[q] += a[q][u];
+                for (int u = 0; u < kKrSlots; ++u) acc[q] = fmaf(a[q][u], m[q][u], acc[q]);
                 cur[q] += kKrSlots;
                 more = more || cur[q] <= last[q];
             }
