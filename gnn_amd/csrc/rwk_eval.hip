@@ -84,12 +84,14 @@ __global__ void __launch_bounds__(kBlock) eval_forward_kernel(const EvalArgs a) 
     // row pointers of this thread's first two nodes: requested now, used after the projection (the thread that
     // projects node p0 + tid (+ 256) is the one that later gathers its neighbours)
     int e_beg[2] = {0, 0}, e_end[2] = {0, 0};
+    float f_first[2] = {0.f, 0.f};             // first feature of the thread's first two nodes (projected input only)
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int local = tid + r * kBlock;
         if (local < ng) {
             e_beg[r] = a.crow[p0 + local];
             e_end[r] = a.crow[p0 + local + 1];
+            if (a.fc_w != nullptr) f_first[r] = a.feat[(size_t)(p0 + local) * a.f];
         }
     }
     if (a.fc_w != nullptr)
@@ -120,7 +122,7 @@ __global__ void __launch_bounds__(kBlock) eval_forward_kernel(const EvalArgs a) 
     }
     // ---- X0 of the graph's nodes
     float4 *x0s = reinterpret_cast<float4 *>(xs);
-    for (int local = tid; local < ng; local += kBlock) {
+    for (int local = tid, r = 0; local < ng; local += kBlock, ++r) {
         const size_t node = (size_t)(p0 + local);
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.fc_w != nullptr) {
@@ -131,7 +133,7 @@ __global__ void __launch_bounds__(kBlock) eval_forward_kernel(const EvalArgs a) 
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[c] = c < d ? fcs[d * a.f + c] : 0.f;
             for (int k = 0; k < a.f; ++k) {
-                const float fv = frow[k];
+                const float fv = (k == 0 && r < 2) ? (r == 0 ? f_first[0] : f_first[1]) : frow[k];
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (c < d) acc[c] = fmaf(fv, fcs[c * a.f + k], acc[c]);
@@ -333,9 +335,11 @@ __global__ void __launch_bounds__(kBlock) x_chain_hidden_kernel(const XChainArgs
     const int g = (int)blockIdx.x - a.h;
     const int p0 = a.seg_ptr[g], ng = a.seg_ptr[g + 1] - p0;
     int e_beg[2] = {0, 0}, e_end[2] = {0, 0};
-#pragma unroll
+    float f_first[2] = {0.f, 0.f};             // the first feature of the thread's first two nodes, requested with the
+#pragma unroll                                 // row pointers (in the loop below each cost a trip of its own)
     for (int r = 0; r < 2; ++r) {
         const int local = tid + r * kBlock;
+        if (local < ng) f_first[r] = a.feat[(size_t)(p0 + local) * a.f];
         if (local < ng && a.steps > 1) {
             e_beg[r] = a.crow[p0 + local];
             e_end[r] = a.crow[p0 + local + 1];
@@ -344,14 +348,14 @@ __global__ void __launch_bounds__(kBlock) x_chain_hidden_kernel(const XChainArgs
     for (int i = tid; i < 4 * a.f + 4; i += kBlock) fcs[i] = i < 4 * a.f ? a.fc_w[i] : a.fc_b[i - 4 * a.f];
     __syncthreads();
     float4 *x0g = reinterpret_cast<float4 *>(a.xs);
-    for (int local = tid; local < ng; local += kBlock) {
+    for (int local = tid, r = 0; local < ng; local += kBlock, ++r) {
         const size_t node = (size_t)(p0 + local);
         const float *frow = a.feat + node * a.f;
         float acc[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = fcs[4 * a.f + c];
         for (int k = 0; k < a.f; ++k) {
-            const float fv = frow[k];
+            const float fv = (k == 0 && r < 2) ? (r == 0 ? f_first[0] : f_first[1]) : frow[k];
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[c] = fmaf(fv, fcs[c * a.f + k], acc[c]);
         }
