@@ -237,8 +237,17 @@ __device__ inline void spmm_tile_body(int bid, int nblocks, const int32_t *__res
     const int r0 = lb * RPW;
     const int col_base = sizeof(COLT) == 2 ? (r0 & ~(kColBlock - 1)) : 0;
     const int nrows = n - r0 < RPW ? n - r0 : RPW;
-    for (int i = tid; i <= nrows; i += kBlock) s_crow[i] = crow[r0 + i];
-    if (tid == 0) s_nlong = 0;
+    // the block's RPW + 1 row pointers: one per thread and the last one, both requested before either is stored (as a
+    // loop over i = tid, tid + 256 the second round - one thread's load - was a trip to memory of its own)
+    {
+        const int cv = crow[r0 + (tid <= nrows ? tid : nrows)];
+        const int cl = crow[r0 + nrows];
+        if (tid <= nrows) s_crow[tid] = cv;
+        if (tid == 0) {
+            s_crow[nrows] = cl;
+            s_nlong = 0;
+        }
+    }
     __syncthreads();
     const int e0 = s_crow[0], e1 = s_crow[nrows];
     const bool has_row = slot < nrows;
