@@ -38,24 +38,52 @@ spmm_csr_kernel(const int32_t *__restrict__ crow, const int32_t *__restrict__ co
     const bool skipped = active && !row_list && skip_above > 0 && (end - beg) > skip_above;
     if (skipped) end = beg;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j = beg + r; j < end; j += r_lanes) {
-        const int c = col[j];
-        const float v = val[j];
-        float4 xv;
-        if (ALIGNED) {
-            xv = *reinterpret_cast<const float4 *>(x + (size_t)c * d + 4 * sub);
-        } else {
+    // Aligned rows, four entries of the lane's share per pass: their columns and values are requested together,
+    // then the four x rows, then the sums in the order of the entries (a one-entry loop waits for each column before
+    // it can ask for the x row behind it, two trips to memory per entry).  An entry past the row's end is loaded at
+    // the pass's first index and enters the sum with the value 0.0f (a branch around it would put its loads behind
+    // a wait).  Unaligned rows (four scalar loads per x row, fewer in the row's last chunk) measured no better
+    // that way and keep the one-entry loop.
+    if constexpr (ALIGNED) {
+        constexpr int U = 4;
+        for (int j = beg + r; j < end; j += U * r_lanes) {
+            int c[U];
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int jj = j + u * r_lanes;
+                const bool ok = jj < end;
+                const int jc = ok ? jj : j;
+                c[u] = col[jc];
+                v[u] = val[jc] * (ok ? 1.f : 0.f);
+            }
+            float4 xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) xv[u] = *reinterpret_cast<const float4 *>(x + (size_t)c[u] * d + 4 * sub);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc.x = fmaf(v[u], xv[u].x, acc.x);
+                acc.y = fmaf(v[u], xv[u].y, acc.y);
+                acc.z = fmaf(v[u], xv[u].z, acc.z);
+                acc.w = fmaf(v[u], xv[u].w, acc.w);
+            }
+        }
+    } else {
+        for (int j = beg + r; j < end; j += r_lanes) {
+            const int c = col[j];
+            const float v = val[j];
             const float *xr = x + (size_t)c * d;
             const int b = 4 * sub;
+            float4 xv;
             xv.x = b + 0 < d ? xr[b + 0] : 0.f;
             xv.y = b + 1 < d ? xr[b + 1] : 0.f;
             xv.z = b + 2 < d ? xr[b + 2] : 0.f;
             xv.w = b + 3 < d ? xr[b + 3] : 0.f;
+            acc.x = fmaf(v, xv.x, acc.x);
+            acc.y = fmaf(v, xv.y, acc.y);
+            acc.z = fmaf(v, xv.z, acc.z);
+            acc.w = fmaf(v, xv.w, acc.w);
         }
-        acc.x = fmaf(v, xv.x, acc.x);
-        acc.y = fmaf(v, xv.y, acc.y);
-        acc.z = fmaf(v, xv.z, acc.z);
-        acc.w = fmaf(v, xv.w, acc.w);
     }
     // sum the R shares: lanes q and q ^ (VEC*k) hold the same float4 chunk
     for (int off = VEC; off < group_lanes; off <<= 1) {
