@@ -1606,8 +1606,10 @@ __global__ void __launch_bounds__(kBlock)
 head_bwd_finish_kernel(const float *__restrict__ k, HeadDims dm, const float *__restrict__ bn_w,
                        const float *__restrict__ mean, const float *__restrict__ invstd,
                        const float *__restrict__ dy, const float *__restrict__ partials, int n_partials, int training,
-                       float *__restrict__ grads, float *__restrict__ d_k, const float *__restrict__ d_loss,
-                       const float *__restrict__ loss_partials, float *__restrict__ loss_out) {
+                       float *grads, float *__restrict__ d_k, const float *__restrict__ d_loss,
+                       const float *__restrict__ loss_partials, float *__restrict__ loss_out, int cols_ready) {
+    // cols_ready: an earlier launch (this kernel with d_k = nullptr) has written grads; this one only forms dK and
+    // takes the gamma / beta column sums from grads instead of adding the block partials up again.
     __shared__ float s_dga[kMaxC], s_dbe[kMaxC];
     const int c = dm.c, p = dm.p, nc = dm.nc;
     const int nv = head_nv(c, p, nc);
@@ -1646,10 +1648,19 @@ head_bwd_finish_kernel(const float *__restrict__ k, HeadDims dm, const float *__
     const int n_cols2 = d_k != nullptr ? 2 * c : 0;
     const long long n_tiles = (dm.g + kRows - 1) / kRows;
     RwkFinPartials pre_e, pre_c[2];
-    if (e_lo < e_hi) pre_e.load(partials, n_partials, nv, e_lo + grp < e_hi ? e_lo + grp : e_hi - 1, lane8);
+    float ready_col[kMaxC * 2 / kBlock];
+    if (cols_ready) {
+#pragma unroll
+        for (int u = 0; u < kMaxC * 2 / kBlock; ++u) {
+            const int q = tid + u * kBlock;
+            ready_col[u] = grads[o_ga + (q < 2 * c ? q : 2 * c - 1)];
+        }
+    }
+    if (!cols_ready && e_lo < e_hi)
+        pre_e.load(partials, n_partials, nv, e_lo + grp < e_hi ? e_lo + grp : e_hi - 1, lane8);
 #pragma unroll
     for (int it = 0; it < 2; ++it)
-        if (it * (kBlock / 8) < n_cols2) {
+        if (!cols_ready && it * (kBlock / 8) < n_cols2) {
             const int q = it * (kBlock / 8) + grp;
             pre_c[it].load(partials, n_partials, nv, o_ga + (q < 2 * c ? q : 2 * c - 1), lane8);
         }
@@ -1666,7 +1677,7 @@ head_bwd_finish_kernel(const float *__restrict__ k, HeadDims dm, const float *__
         t_sc = bn_w[col] * t_is;
         t_mu = mean[col];
     }
-    for (int e0 = e_lo; e0 < e_hi; e0 += kBlock / 8) {      // uniform trip count: the butterfly needs all lanes
+    for (int e0 = e_lo; e0 < (cols_ready ? e_lo : e_hi); e0 += kBlock / 8) {   // uniform trip count: the butterfly needs all lanes
         const int e = e0 + grp;
         const int ec = e < e_hi ? e : e_hi - 1;
         float acc = e0 == e_lo ? pre_e.sum(partials, n_partials, nv, ec, lane8)
@@ -1678,7 +1689,15 @@ head_bwd_finish_kernel(const float *__restrict__ k, HeadDims dm, const float *__
         finish_loss();
         return;
     }
-    for (int c0 = 0; c0 < 2 * c; c0 += kBlock / 8) {
+    if (cols_ready) {
+#pragma unroll
+        for (int u = 0; u < kMaxC * 2 / kBlock; ++u) {
+            const int q = tid + u * kBlock;
+            if (q < c) s_dga[q] = ready_col[u];
+            else if (q < 2 * c) s_dbe[q - c] = ready_col[u];
+        }
+    }
+    for (int c0 = 0; c0 < (cols_ready ? 0 : 2 * c); c0 += kBlock / 8) {
         const int q = c0 + grp;                              // q < c: dgamma column, else dbeta column
         const int qc = q < 2 * c ? q : 2 * c - 1;
         float acc;
@@ -1706,6 +1725,27 @@ head_bwd_finish_kernel(const float *__restrict__ k, HeadDims dm, const float *__
         }
     }
     finish_loss();
+}
+
+// One launch while the gamma / beta columns fit the kernel's prefetch (2 c <= 64).  Wider heads take two: every
+// workgroup of the single launch adds up all 2 c columns of all block partials before it can form a dK row
+// (c = 128, 256 partials: 256 KB from L2 and sixteen dependent trips per workgroup, 22 us on 4096 graphs); split, the
+// first launch forms each parameter gradient once (32 elements per workgroup, one trip) and the second reads the
+// 2 c column sums it needs from there.  Same sums in the same order either way.
+inline void launch_finish(hipStream_t stream, const float *k, const HeadDims &dm, const float *bn_w, const float *mean,
+                          const float *invstd, const float *dy, const float *partials, int blocks, int training,
+                          float *grads, float *d_k, const float *d_loss, const float *loss_partials, float *loss) {
+    if (d_k == nullptr || 2 * dm.c <= 2 * (kBlock / 8)) {
+        hipLaunchKernelGGL(head_bwd_finish_kernel, dim3(finish_grid(blocks, dm.c, dm.p, dm.nc)), dim3(kBlock), 0, stream,
+                           k, dm, bn_w, mean, invstd, dy, partials, blocks, training, grads, d_k, d_loss, loss_partials,
+                           loss, 0);
+        return;
+    }
+    const int by_elements = (head_nv(dm.c, dm.p, dm.nc) + kBlock / 8 - 1) / (kBlock / 8);
+    hipLaunchKernelGGL(head_bwd_finish_kernel, dim3(by_elements), dim3(kBlock), 0, stream, k, dm, bn_w, mean, invstd, dy,
+                       partials, blocks, training, grads, (float *)nullptr, d_loss, loss_partials, loss, 0);
+    hipLaunchKernelGGL(head_bwd_finish_kernel, dim3(blocks), dim3(kBlock), 0, stream, k, dm, bn_w, mean, invstd, dy,
+                       partials, blocks, training, grads, d_k, d_loss, (const float *)nullptr, (float *)nullptr, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2003,9 +2043,8 @@ int rwk_head_backward_loss(const float *k, int64_t g, int64_t c, int64_t p, int6
                        w1, w2, h1d, out, d_out, keep_scale, dy, partials, (const long long *)labels, d_loss,
                        loss_partials, blocks, loss);
     RWK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(head_bwd_finish_kernel, dim3(finish_grid(blocks, (int)c, (int)p, (int)nc)), dim3(kBlock), 0,
-                       stream, k, dm, bn_w, mean, invstd, dy, partials, blocks, training, grads, d_k,
-                       (const float *)nullptr, (const float *)nullptr, (float *)nullptr);
+    launch_finish(stream, k, dm, bn_w, mean, invstd, dy, partials, blocks, training, grads, d_k,
+                  (const float *)nullptr, (const float *)nullptr, (float *)nullptr);
     RWK_LAUNCH_CHECK();
     return RWK_OK;
 }
@@ -2094,9 +2133,8 @@ int rwk_head_train_backward(const float *k, int64_t g, int64_t c, int64_t p, int
     if (!rwk_head_train_supported(g, c, p, nc)) return RWK_E_UNSUPPORTED;
     const int blocks = head_blocks(g);
     const HeadDims dm{(long long)g, (int)c, (int)p, (int)nc};
-    hipLaunchKernelGGL(head_bwd_finish_kernel, dim3(finish_grid(blocks, (int)c, (int)p, (int)nc)), dim3(kBlock), 0,
-                       (hipStream_t)stream_, k, dm, bn_w, mean, invstd, dy, partials, blocks, 1, grads, d_k, d_loss,
-                       loss_partials, loss);
+    launch_finish((hipStream_t)stream_, k, dm, bn_w, mean, invstd, dy, partials, blocks, 1, grads, d_k, d_loss,
+                  loss_partials, loss);
     RWK_LAUNCH_CHECK();
     return RWK_OK;
 }

@@ -22,34 +22,36 @@ struct RwkFinPartials {
 #pragma unroll
         for (int u = 0; u < 16; ++u) acc += lane8 + 8 * u < n_partials ? v[u] : 0.f;
         for (int b0 = lane8 + 128; b0 < n_partials; b0 += 64) {
-            float w[8];
+            float w[8], m[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int b = b0 + 8 * u;
                 w[u] = partials[(size_t)(b < n_partials ? b : n_partials - 1) * nv + e];
-                if (b >= n_partials) w[u] = 0.f;
+                m[u] = b < n_partials ? 1.f : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc += w[u];
+            for (int u = 0; u < 8; ++u) acc = fmaf(w[u], m[u], acc);
         }
         return acc;
     }
 };
 
-// partials[b][e] added over b = lane8, lane8 + 8, ... in that order, eight loads in flight at a time
+// partials[b][e] added over b = lane8, lane8 + 8, ... in that order, eight loads in flight at a time.  A block past
+// the last one is loaded at the last block's index and enters the sum times 0.0f: with a select on the loaded value
+// the compiler branches around each load and waits for each in turn (eight trips to memory instead of one).
 __device__ static inline float rwk_sum_partials8(const float *__restrict__ partials, int n_partials, int nv, int e,
                                                  int lane8) {
     float acc = 0.f;
     for (int b0 = lane8; b0 < n_partials; b0 += 64) {
-        float v[8];
+        float v[8], m[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int b = b0 + 8 * u;
             v[u] = partials[(size_t)(b < n_partials ? b : n_partials - 1) * nv + e];
-            if (b >= n_partials) v[u] = 0.f;
+            m[u] = b < n_partials ? 1.f : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u];
+        for (int u = 0; u < 8; ++u) acc = fmaf(v[u], m[u], acc);
     }
     return acc;
 }
