@@ -18,13 +18,13 @@ def golden_dir():
 
 
 def pytest_collection_finish(session):
-    """Start the two-rank data-parallel job of tests/test_gpu_dp2.py now: child processes are created before this
+    """Start the two-rank data-parallel job of tests/test_zy_gpu_dp2.py now: child processes are created before this
     process makes any GPU call; they import their modules and wait for the test's go-ahead, so they never share the
     device with other tests.  Nothing happens when that test is deselected
     (the CPU run) or no device is visible."""
     if session.config.option.collectonly:
         return
-    if not any(os.path.basename(str(i.fspath)) == "test_gpu_dp2.py" for i in session.items):
+    if not any(os.path.basename(str(i.fspath)) == "test_zy_gpu_dp2.py" for i in session.items):
         return
     import socket
     import subprocess

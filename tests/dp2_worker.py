@@ -23,6 +23,7 @@ def main(outdir):
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     result = {"rank": rank, "ok": False}
+    import faulthandler
     try:
         # Everything is imported; the GPU work waits until the test asks for it (the file "go"), so that the ranks do
         # not share the device with whatever other tests the session is running meanwhile.
@@ -33,6 +34,9 @@ def main(outdir):
                 result.update(ok=True, skipped="the test that starts the ranks never ran")
                 return result
             time.sleep(0.05)
+        # the GPU part takes seconds: a rank still here after four minutes writes every thread's stack to the log
+        # (stderr) and exits, so that a hang names the call it sits in
+        faulthandler.dump_traceback_later(240, exit=True)
         if not torch.cuda.is_available():
             result.update(ok=True, skipped="no GPU")
             return result

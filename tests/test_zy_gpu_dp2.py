@@ -1,7 +1,10 @@
 """Two real processes stepping the HIP kernels: each rank trains on its ``shard_ranges`` share of one batch, gradients
 all-reduced over gloo (both ranks share the one GPU of the box).  The ranks are started by ``tests/conftest.py`` when
 the collection ends - before this process makes its first GPU call - import what they need and wait; this test gives
-them the go-ahead, waits for them and reads their verdicts (``tests/dp2_worker.py`` documents what each rank checks)."""
+them the go-ahead, waits for them and reads their verdicts (``tests/dp2_worker.py`` documents what each rank checks).
+The file's name puts it near the end of the collection: processes that share one GPU have hung in the runtime on this
+pool now and then (a rank that makes no progress dumps its stack into the job's log after four minutes and exits),
+and under ``pytest -x`` a failure here should not hide the single-process tests."""
 import json
 import os
 
