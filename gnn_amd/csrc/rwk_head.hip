@@ -1727,7 +1727,8 @@ head_bwd_finish_kernel(const float *__restrict__ k, HeadDims dm, const float *__
     finish_loss();
 }
 
-// One launch while the gamma / beta columns fit the kernel's prefetch (2 c <= 64).  Wider heads take two: every
+// One launch while the gamma / beta columns fit the kernel's prefetch (2 c <= 64) or nearly so.  Wider heads on
+// batches with many block partials take two: every
 // workgroup of the single launch adds up all 2 c columns of all block partials before it can form a dK row
 // (c = 128, 256 partials: 256 KB from L2 and sixteen dependent trips per workgroup, 22 us on 4096 graphs); split, the
 // first launch forms each parameter gradient once (32 elements per workgroup, one trip) and the second reads the
@@ -1735,7 +1736,10 @@ head_bwd_finish_kernel(const float *__restrict__ k, HeadDims dm, const float *__
 inline void launch_finish(hipStream_t stream, const float *k, const HeadDims &dm, const float *bn_w, const float *mean,
                           const float *invstd, const float *dy, const float *partials, int blocks, int training,
                           float *grads, float *d_k, const float *d_loss, const float *loss_partials, float *loss) {
-    if (d_k == nullptr || 2 * dm.c <= 2 * (kBlock / 8)) {
+    // dependent trips the single launch makes beyond its prefetch: a round per 32 further columns, each a trip per 64
+    // block partials; a second launch costs about three of them
+    const int extra_trips = ((2 * dm.c - 1) / (kBlock / 8) - 1) * ((blocks + 63) / 64);
+    if (d_k == nullptr || extra_trips <= 6) {
         hipLaunchKernelGGL(head_bwd_finish_kernel, dim3(finish_grid(blocks, dm.c, dm.p, dm.nc)), dim3(kBlock), 0, stream,
                            k, dm, bn_w, mean, invstd, dy, partials, blocks, training, grads, d_k, d_loss, loss_partials,
                            loss, 0);
