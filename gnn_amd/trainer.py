@@ -258,13 +258,31 @@ class Trainer:
             torch.cuda.synchronize()
             note = "multi-step capture refused (%s: %s)" % (type(exc).__name__, str(exc)[:200])
             self.capture_note = (self.capture_note + "; " if self.capture_note else "") + note
+        if collective and not self._all_ranks(self.multi_k == int(steps_per_graph)):
+            # some rank has no multi-step graph: every rank replays single steps, so that all of them issue the
+            # collectives from the same kind of launch
+            if self.multi_k > 1:
+                self.capture_note += "; multi-step graph dropped (another rank refused the capture)"
+            self.g_multi, self.losses, self.multi_k = None, [], 1
         self.loss = self._single_loss  # step_graph() leaves its loss here; run_steps() points it at the last one
+
+    def _all_ranks(self, ok: bool) -> bool:
+        """True when ``ok`` holds on every rank (one eager MIN all-reduce; every rank must call it at the same point,
+        whatever its own outcome, so that a capture refused on some ranks only cannot leave the others waiting in a
+        collective nobody else issues)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return bool(ok)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.bucket.flat.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
 
     def _capture_single_graph(self) -> bool:
         """forward+backward, all-reduce and update in one graph.  Returns False (with everything as it was before,
         the reason in ``capture_note``) when the capture raises or when a replay does not leave the averaged
         gradient in the bucket."""
         g = torch.cuda.CUDAGraph()
+        captured = True
         try:
             with torch.cuda.graph(g, capture_error_mode=self.capture_error_mode):
                 self.fwd_bwd()
@@ -276,6 +294,12 @@ class Trainer:
         except Exception as exc:                         # refused by the runtime or the collective library
             self.capture_note = "all-reduce capture refused (%s: %s)" % (type(exc).__name__, str(exc)[:200])
             torch.cuda.synchronize()
+            captured = False
+        # the ranks agree before any of them replays the graph: its all-reduce would wait for ranks that have none
+        if not self._all_ranks(captured):
+            if captured:
+                self.capture_note = "all-reduce capture refused on another rank; two graphs instead"
+            del g
             self.loss = None
             return False
         # one replay, then the same sum done eagerly: every rank must hold identical (averaged) gradients, so the
