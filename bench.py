@@ -516,11 +516,15 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     # RWK_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share devices,
     # the all-reduce goes through the host); the measured runs use nccl (= RCCL), one rank per GPU.
+    import faulthandler
     if os.environ.get("RWK_BENCH_TRACE"):            # hang diagnosis: dump every thread's stack after N seconds
-        import faulthandler
         os.makedirs("gpurun_out", exist_ok=True)
         faulthandler.dump_traceback_later(int(os.environ["RWK_BENCH_TRACE"]),
                                           file=open("gpurun_out/trace_rank%d.txt" % rank, "w"), exit=True)
+    else:
+        # a run still going after fifteen minutes writes every thread's stack to stderr once and carries on: a rank
+        # stuck in a collective or a synchronize then names the call it sits in
+        faulthandler.dump_traceback_later(900, exit=False)
     backend = os.environ.get("RWK_DIST_BACKEND", "nccl")
     if backend != "nccl":
         local_rank %= max(torch.cuda.device_count(), 1)
