@@ -304,6 +304,9 @@ __global__ void __launch_bounds__(kBlock) eval_forward_kernel(const EvalArgs a) 
 // launch did nothing but wait for rows the projection had just written.  Same operations in the same order as those
 // launches for rows below the tile SpMM's hub length (an fmaf chain in stored order): same bits.
 // ---------------------------------------------------------------------------------------------------------
+constexpr int kXChainColsPerNode = 8;     // LDS reserved for a graph's columns: this many 16-bit entries per node
+constexpr int kXChainColsPre = 6;         // column loads per thread in flight under the projection (1536 entries)
+
 struct XChainArgs {
     const float *feat;
     int f;
@@ -331,6 +334,8 @@ __global__ void __launch_bounds__(kBlock) x_chain_hidden_kernel(const XChainArgs
     float4 *xa = reinterpret_cast<float4 *>(lds);              // [max_nodes]: the previous step's rows
     float4 *xb = xa + a.max_nodes;                             // [max_nodes]: this step's
     float *fcs = reinterpret_cast<float *>(xb + a.max_nodes);  // [4 * f + 4]
+    // [kXChainColsPerNode * max_nodes] columns of the graph's rows, as distances from its first node
+    unsigned short *cols = reinterpret_cast<unsigned short *>(fcs + 4 * a.f + 4);
     const int tid = threadIdx.x;
     const int g = (int)blockIdx.x - a.h;
     const int p0 = a.seg_ptr[g], ng = a.seg_ptr[g + 1] - p0;
@@ -345,8 +350,28 @@ __global__ void __launch_bounds__(kBlock) x_chain_hidden_kernel(const XChainArgs
             e_end[r] = a.crow[p0 + local + 1];
         }
     }
+    // The stored entries of the graph's rows are one contiguous range: with its two ends (requested here, with the row
+    // pointers) the whole range of columns is fetched coalesced while the projection below runs, and every
+    // propagation step reads its columns from LDS.  Read row by row from memory they were one to three more
+    // dependent trips per step (four entries a trip, and a wavefront waits for its longest row).  Unweighted graphs
+    // below 65536 nodes whose entries fit the reserved space; others read memory as before.
+    int ge0 = 0, ge1 = 0;
+    if (a.steps > 1 && a.val == nullptr) {
+        ge0 = a.crow[p0];
+        ge1 = a.crow[p0 + ng];
+    }
     for (int i = tid; i < 4 * a.f + 4; i += kBlock) fcs[i] = i < 4 * a.f ? a.fc_w[i] : a.fc_b[i - 4 * a.f];
     __syncthreads();
+    const int n_e = ge1 - ge0;
+    const bool cols_in_lds = n_e > 0 && n_e <= kXChainColsPerNode * a.max_nodes && ng <= 65536;
+    int pre_c[kXChainColsPre];
+    if (cols_in_lds) {
+#pragma unroll
+        for (int u = 0; u < kXChainColsPre; ++u) {
+            const int i = tid + u * kBlock;
+            pre_c[u] = a.col[ge0 + (i < n_e ? i : n_e - 1)];
+        }
+    }
     float4 *x0g = reinterpret_cast<float4 *>(a.xs);
     for (int local = tid, r = 0; local < ng; local += kBlock, ++r) {
         const size_t node = (size_t)(p0 + local);
@@ -364,6 +389,14 @@ __global__ void __launch_bounds__(kBlock) x_chain_hidden_kernel(const XChainArgs
         xa[local] = v;
         x0g[node] = v;
     }
+    if (cols_in_lds) {
+#pragma unroll
+        for (int u = 0; u < kXChainColsPre; ++u) {
+            const int i = tid + u * kBlock;
+            if (i < n_e) cols[i] = (unsigned short)(pre_c[u] - p0);
+        }
+        for (int i = tid + kXChainColsPre * kBlock; i < n_e; i += kBlock) cols[i] = (unsigned short)(a.col[ge0 + i] - p0);
+    }
     __syncthreads();
     for (int i = 1; i < a.steps; ++i) {
         float4 *xg = reinterpret_cast<float4 *>(a.xs) + (size_t)i * a.n;
@@ -372,6 +405,16 @@ __global__ void __launch_bounds__(kBlock) x_chain_hidden_kernel(const XChainArgs
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             const int e0 = r == 0 ? e_beg[0] : r == 1 ? e_beg[1] : a.crow[node];
             const int e1 = r == 0 ? e_end[0] : r == 1 ? e_end[1] : a.crow[node + 1];
+            if (cols_in_lds) {
+                // acc + x is what fmaf(1.0f, x, acc) returns: the same sum in the same (stored) order
+                for (int e = e0 - ge0; e < e1 - ge0; ++e) {
+                    const float4 rr = xa[cols[e]];
+                    acc.x += rr.x; acc.y += rr.y; acc.z += rr.z; acc.w += rr.w;
+                }
+                xb[local] = acc;
+                xg[node] = acc;
+                continue;
+            }
             for (int e = e0; e < e1; e += 4) {
                 int c[4];
                 float w[4];
@@ -413,7 +456,8 @@ extern "C" {
 
 int64_t rwk_x_chain_lds(int64_t f, int64_t max_nodes, int64_t s) {
     if (f < 1 || f > 16 || max_nodes < 1 || s < 1) return 0;
-    const size_t graph = (size_t)(2 * max_nodes * 4 + 4 * f + 4) * sizeof(float);
+    const size_t graph = (size_t)(2 * max_nodes * 4 + 4 * f + 4) * sizeof(float) +
+                         (size_t)kXChainColsPerNode * max_nodes * sizeof(unsigned short);
     const size_t hidden = hidden_forward_lds(s, 4);
     const size_t bytes = graph > hidden ? graph : hidden;
     return bytes <= kLdsBudget ? (int64_t)bytes : 0;
