@@ -174,3 +174,12 @@ __device__ static inline float rwk_group_sum(float v, int width) {
     if (width >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
+
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Every kernel of the step that walks the
+// nodes gives XCD k the k-th contiguous eighth of them (the fused kernels by their streams, the per-graph launches by
+// their graphs, the tile SpMM by its row blocks), so that rows one kernel wrote or read are met in the same L2 by the next.
+__device__ static inline int rwk_xcd_block(int bid, int nblocks) {
+    const int per_xcd = nblocks / 8;
+    return bid < per_xcd * 8 ? (bid % 8) * per_xcd + bid / 8 : bid;
+}
+

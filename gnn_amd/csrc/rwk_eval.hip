@@ -337,7 +337,13 @@ __global__ void __launch_bounds__(kBlock) x_chain_hidden_kernel(const XChainArgs
     // [kXChainColsPerNode * max_nodes] columns of the graph's rows, as distances from its first node
     unsigned short *cols = reinterpret_cast<unsigned short *>(fcs + 4 * a.f + 4);
     const int tid = threadIdx.x;
-    const int g = (int)blockIdx.x - a.h;
+    // XCD k takes the k-th contiguous eighth of the graphs (workgroups are dealt round-robin to the 8 XCDs): the X
+    // rows written here are read by the fused kernels, which give XCD k the k-th eighth of the nodes
+    int g = (int)blockIdx.x - a.h;
+    {
+        const int per_xcd = a.n_graphs / 8;
+        if (g < per_xcd * 8) g = (((int)blockIdx.x) % 8) * per_xcd + g / 8;
+    }
     const int p0 = a.seg_ptr[g], ng = a.seg_ptr[g + 1] - p0;
     int e_beg[2] = {0, 0}, e_end[2] = {0, 0};
     float f_first[2] = {0.f, 0.f};             // the first feature of the thread's first two nodes, requested with the

@@ -277,7 +277,7 @@ forward_kernel(const float *__restrict__ x, const float *__restrict__ z, const i
     const int lane_h = tid % hp;
     const int hh = lane_h < h ? lane_h : h - 1;
     const int group0 = tid - lane_h;                    // first slot of this lane's stream in the tile
-    const int c = blockIdx.x * (kBlock / hp) + tid / hp;
+    const int c = rwk_xcd_block(blockIdx.x, gridDim.x) * (kBlock / hp) + tid / hp;
     const long long start_ll = (long long)c * stream_len;
     const bool has_stream = start_ll < n;
     const int start = has_stream ? (int)start_ll : 0;
@@ -466,7 +466,7 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     const int hh = lane_h < h ? lane_h : h - 1;
     const bool own_h = lane_h < h;
     const int group0 = tid - lane_h;
-    const int c = blockIdx.x * (kBlock / hp) + tid / hp;
+    const int c = rwk_xcd_block(blockIdx.x, gridDim.x) * (kBlock / hp) + tid / hp;
     const long long start_ll = (long long)c * stream_len;
     const bool has_stream = start_ll < n;
     const int start = has_stream ? (int)start_ll : 0;
@@ -756,7 +756,7 @@ backward_kernel(const float *__restrict__ x, const float *__restrict__ z, const 
     }
     // per-workgroup partial of dZ: threads that own the same hidden graph are added in thread order
     const int spb = kBlock / hp;
-    float *out = dz_partials + (size_t)blockIdx.x * LT * h * ST * d;
+    float *out = dz_partials + (size_t)rwk_xcd_block(blockIdx.x, gridDim.x) * LT * h * ST * d;   // the row of the logical block
 #pragma unroll
     for (int cb = 0; cb < V; cb += CH) {
         __syncthreads();
