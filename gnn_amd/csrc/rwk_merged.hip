@@ -23,8 +23,14 @@ project_hidden_forward_kernel(const float *__restrict__ adj_hidden, const float 
     if ((int)blockIdx.x < n_hidden)
         hidden_forward_body(blockIdx.x, lds, adj_hidden, feat_hidden, n_hidden, s, d, max_step, ah_out, z_out, rng_state,
                             rng_used);
-    else
-        project_forward4_body<FP>((int)blockIdx.x - n_hidden, feat, w, b, n, f, x0);
+    else {
+        // XCD k takes the k-th contiguous eighth of the node blocks, as the tile SpMM and the fused kernels that read
+        // these rows do (workgroups are dealt round-robin to the 8 XCDs, each with its own L2)
+        const int nb = (int)gridDim.x - n_hidden, per_xcd = nb / 8;
+        int blk = (int)blockIdx.x - n_hidden;
+        if (blk < per_xcd * 8) blk = ((int)blockIdx.x % 8) * per_xcd + blk / 8;
+        project_forward4_body<FP>(blk, feat, w, b, n, f, x0);
+    }
 }
 
 template <int FP>
