@@ -320,6 +320,7 @@ struct XChainArgs {
     int h, s;
     float *ah, *z;
     unsigned long long *rng_state, *rng_used;
+    int cols_cap;                      // 16-bit column entries the launch's LDS has room for (0: none)
 };
 
 __global__ void __launch_bounds__(kBlock) x_chain_hidden_kernel(const XChainArgs a) {
@@ -369,7 +370,7 @@ __global__ void __launch_bounds__(kBlock) x_chain_hidden_kernel(const XChainArgs
     for (int i = tid; i < 4 * a.f + 4; i += kBlock) fcs[i] = i < 4 * a.f ? a.fc_w[i] : a.fc_b[i - 4 * a.f];
     __syncthreads();
     const int n_e = ge1 - ge0;
-    const bool cols_in_lds = n_e > 0 && n_e <= kXChainColsPerNode * a.max_nodes && ng <= 65536;
+    const bool cols_in_lds = n_e > 0 && n_e <= a.cols_cap && ng <= 65536;
     int pre_c[kXChainColsPre];
     if (cols_in_lds) {
 #pragma unroll
@@ -449,6 +450,10 @@ __global__ void __launch_bounds__(kBlock) x_chain_hidden_kernel(const XChainArgs
     }
 }
 
+inline size_t x_chain_cols_bytes(int64_t max_nodes) {
+    return (size_t)kXChainColsPerNode * max_nodes * sizeof(unsigned short);
+}
+
 inline size_t eval_lds(int64_t h, int64_t s, int64_t l, int64_t max_nodes, int64_t p, int64_t nc) {
     const int64_t lh = l * h;
     return (size_t)(l * h * s * 4 + h * s * s + l * max_nodes * 4 + kWaves * l * 16 + l * 16 + lh + p + nc +
@@ -462,8 +467,9 @@ extern "C" {
 
 int64_t rwk_x_chain_lds(int64_t f, int64_t max_nodes, int64_t s) {
     if (f < 1 || f > 16 || max_nodes < 1 || s < 1) return 0;
-    const size_t graph = (size_t)(2 * max_nodes * 4 + 4 * f + 4) * sizeof(float) +
-                         (size_t)kXChainColsPerNode * max_nodes * sizeof(unsigned short);
+    const size_t rows = (size_t)(2 * max_nodes * 4 + 4 * f + 4) * sizeof(float);
+    const size_t with_cols = rows + x_chain_cols_bytes(max_nodes);
+    const size_t graph = with_cols <= kLdsBudget ? with_cols : rows;   // the columns' space only when it fits
     const size_t hidden = hidden_forward_lds(s, 4);
     const size_t bytes = graph > hidden ? graph : hidden;
     return bytes <= kLdsBudget ? (int64_t)bytes : 0;
@@ -496,7 +502,11 @@ int rwk_x_chain_hidden_forward(const float *features, const float *weight, const
     }
     XChainArgs a{features, (int)f, weight, bias, crow, col, val, seg_ptr, (int)n, (int)n_graphs, (int)max_nodes,
                  (int)max_step, xs, adj_hidden, features_hidden, (int)h, (int)s, ah, z,
-                 (unsigned long long *)rng_state, (unsigned long long *)rng_used};
+                 (unsigned long long *)rng_state, (unsigned long long *)rng_used, 0};
+    {
+        const size_t rows = (size_t)(2 * max_nodes * 4 + 4 * f + 4) * sizeof(float);
+        if (rows + x_chain_cols_bytes(max_nodes) <= kLdsBudget) a.cols_cap = (int)(kXChainColsPerNode * max_nodes);
+    }
     hipLaunchKernelGGL(x_chain_hidden_kernel, dim3((unsigned)(n_graphs + h)), dim3(kBlock), (size_t)bytes,
                        (hipStream_t)stream, a);
     RWK_LAUNCH_CHECK();
