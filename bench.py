@@ -421,8 +421,9 @@ class StreamBench:
                     ", each as one library call on the slot's buffers" if self.tr.raw_steps else ""))
 
 
-def stream_extra(config, dev, pool_batches=31, steps=62, warmup=8):
-    """The streamed pass of a configuration as an extra key of the default line."""
+def stream_extra(config, dev, pool_batches=31, steps=62, warmup=31):
+    """The streamed pass of a configuration as an extra key of the default line: one whole pass over the pool untimed
+    (every slot and workspace has met its largest batch, the clocks have settled), then whole passes timed."""
     from gnn_amd.synth import CONFIGS
     hp = dict(CONFIGS[config]["hp"])
     sb = StreamBench(config, hp, dev, pool_batches, seed=4321)
