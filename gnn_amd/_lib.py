@@ -136,6 +136,8 @@ SIGNATURES = {
     "rwk_model_forward": (c_int, [_P, _P, _P, _P, _P]),
     "rwk_model_backward": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "rwk_model_train_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "rwk_model_train_pass_plan": (c_int, [_P, _P, _I64, _P, _I64, _P, _P]),
+    "rwk_model_train_pass": (c_int, [_P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int]),
 }
 
 _lib = None

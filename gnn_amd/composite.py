@@ -64,6 +64,35 @@ class TrainTail(ctypes.Structure):
     ]
 
 
+class PassDataset(ctypes.Structure):
+    """``rwk_pass_dataset_t`` of include/rwk.h."""
+    _fields_ = [("row_ptr", c_void_p), ("col", c_void_p), ("val", c_void_p), ("features", c_void_p),
+                ("n_feat", c_int64), ("y", c_void_p), ("unit_values", c_int32), ("reserved", c_int32)]
+
+
+class PassSlot(ctypes.Structure):
+    """``rwk_pass_slot_t`` of include/rwk.h."""
+    _fields_ = [("feats", c_void_p), ("y", c_void_p), ("crow", c_void_p), ("col", c_void_p), ("val", c_void_p),
+                ("col16", c_void_p), ("gid", c_void_p), ("seg_ptr", c_void_p), ("counts_f32", c_void_p)]
+
+
+class PassBatch(ctypes.Structure):
+    """``rwk_pass_batch_t`` of include/rwk.h."""
+    _fields_ = [("b", c_int64), ("n", c_int64), ("nnz", c_int64), ("max_graph_nodes", c_int64),
+                ("table_off", c_int64), ("max_degree", c_int32), ("fits16", c_int32), ("long_threshold", c_int32),
+                ("reserved", c_int32)]
+
+
+class PassNeed(ctypes.Structure):
+    """``rwk_pass_need_t`` of include/rwk.h."""
+    _fields_ = [("served", c_int64), ("train_step", c_int64), ("forward_bytes", c_int64),
+                ("backward_bytes", c_int64), ("grad_floats", c_int64), ("out_floats", c_int64)]
+
+
+#: ``StreamTrainer`` issues the steps of a pass through ``rwk_model_train_pass`` (one library call for all of them);
+#: False keeps one ``rwk_model_train_step`` call per batch (tests compare the two)
+ONE_CALL_PASS = True
+
 _PARAM_FIELDS = ("fc_w", "fc_b", "adj_hidden", "features_hidden", "bn_w", "bn_b", "w1", "b1", "w2", "b2")
 
 
@@ -296,6 +325,104 @@ class TrainStep:
         tr.loss = self._launch(lib, model, m, plan, slot.y.data_ptr(), b, slot.feats.device)
         return True
 
+    @staticmethod
+    def _point_at_model(m, model):
+        """The parameter, running-statistics and generator-state addresses of ``model`` into the step struct."""
+        mods, own = model._modules, model._parameters
+        fc, bn, fc1, fc2 = (mods[k]._parameters for k in ("fc", "bn", "fc1", "fc2"))
+        m.adj_hidden, m.features_hidden = own["adj_hidden"].data_ptr(), own["features_hidden"].data_ptr()
+        m.fc_w, m.fc_b = fc["weight"].data_ptr(), fc["bias"].data_ptr()
+        m.bn_w, m.bn_b = bn["weight"].data_ptr(), bn["bias"].data_ptr()
+        m.w1, m.b1 = fc1["weight"].data_ptr(), fc1["bias"].data_ptr()
+        m.w2, m.b2 = fc2["weight"].data_ptr(), fc2["bias"].data_ptr()
+        buf = mods["bn"]._buffers
+        m.running_mean, m.running_var = buf["running_mean"].data_ptr(), buf["running_var"].data_ptr()
+        m.num_batches_tracked = _lib.ptr(buf["num_batches_tracked"])
+        m.rng_state = model._buffers["_rng_state"].data_ptr() if m.drop_p > 0.0 else None
+
+    def _grads_to_params(self):
+        """The parameters' gradients: the flat bucket the last launch filled, as zero_grad / backward would leave
+        them."""
+        tr = self.trainer
+        views = self.flat_views
+        if views is None or views[0] is not tr.bucket.flat:
+            flat, off, vs = tr.bucket.flat, 0, []
+            for p in tr.bucket.params:
+                vs.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            views = self.flat_views = (flat, vs)
+        for p, v in zip(tr.bucket.params, views[1]):
+            p.grad = v
+
+    def run_pass_slots(self, model, dataset, slots, plan, t0: int, main_stream: int, side_stream):
+        """The steps of batches ``t0, t0 + 1, ...`` of ``plan``, each assembled into slot ``t % len(slots)`` right
+        before it (``side_stream``: a raw handle, or None for the assembly on the launch stream), as ONE library call
+        (``rwk_model_train_pass``).  Returns (k, losses): the number of batches stepped - the call stops in front of a
+        batch it does not serve, 0 when that is batch ``t0`` - and their losses as one tensor of k elements."""
+        lib = _lib.load()
+        tr = self.trainer
+        mods = model._modules
+        bn = mods["bn"]
+        h, s, _ = model._parameters["features_hidden"].shape
+        n_b = len(plan.metas) - t0
+        depth = len(slots)
+        if n_b <= 0 or depth > 8 or bn.num_features != h * int(model.max_step) or not bn.affine \
+                or not bn.track_running_stats or bn.momentum is None or not model.fused_head:
+            return 0, None
+        dev = dataset.device
+        drop = float(mods["dropout"].p)
+        m = ModelStep()
+        m.f, m.d, m.h, m.s, m.max_step = dataset.n_feat, 4, h, s, int(model.max_step)
+        m.p, m.nc = mods["fc1"].out_features, mods["fc2"].out_features
+        m.normalize = int(bool(model.normalize))
+        m.drop_p, m.momentum, m.eps = drop, float(bn.momentum), float(bn.eps)
+        if drop > 0.0 and not model._rng_seeded:
+            model._seed_from_torch()
+        self._point_at_model(m, model)
+        ds = getattr(dataset, "_pass_struct", None)
+        if ds is None:
+            ds = PassDataset()
+            ds.row_ptr, ds.col, ds.val = dataset.row_ptr.data_ptr(), _lib.ptr(dataset.col), _lib.ptr(dataset.val)
+            ds.features, ds.n_feat, ds.y = dataset.features.data_ptr(), dataset.n_feat, dataset.y.data_ptr()
+            ds.unit_values = int(bool(dataset.unit_values))
+            dataset._pass_struct = ds
+        cs = (PassSlot * depth)()
+        for j in range(depth):                       # batch t0 + j goes to slot (t0 + j) % depth
+            sl, c = slots[(t0 + j) % depth], cs[j]
+            c.feats, c.y, c.crow, c.col, c.val = (sl.feats.data_ptr(), sl.y.data_ptr(), sl.crow.data_ptr(),
+                                                  sl.col.data_ptr(), sl.val.data_ptr())
+            c.col16 = _lib.ptr(sl.col16)
+            c.gid, c.seg_ptr, c.counts_f32 = sl.gid.data_ptr(), sl.seg_ptr.data_ptr(), sl.counts_f32.data_ptr()
+        batches = plan.pass_batches(PassBatch)
+        first = ctypes.byref(batches, t0 * ctypes.sizeof(PassBatch))
+        need = PassNeed()
+        _lib.check(lib.rwk_model_train_pass_plan(ctypes.byref(ds), first, n_b, cs, depth, ctypes.byref(m),
+                                                 ctypes.byref(need)), "rwk_model_train_pass_plan")
+        k = int(need.served)
+        if k == 0:
+            return 0, None
+        for meta in plan.metas[t0:t0 + k]:
+            if meta[6] < 0 or meta[7] >= m.nc:
+                raise IndexError(f"Target {meta[6] if meta[6] < 0 else meta[7]} is out of bounds for {m.nc} classes")
+        with _lib.device_guard(dev):
+            fws = self._room(0, need.forward_bytes, torch.uint8, dev)
+            bws = self._room(1, need.backward_bytes, torch.uint8, dev)
+            grads = self._room(2, need.grad_floats, torch.float32, dev)
+            out = self._room(3, need.out_floats, torch.float32, dev)
+            losses = torch.empty(k, dtype=torch.float32, device=dev)
+            fold = need.train_step == 1
+            t = self._tail(lib, "head" if fold else "plain")
+            _lib.check(lib.rwk_model_train_pass(
+                ctypes.byref(ds), plan.tables.data_ptr(), first, k, cs, depth, ctypes.byref(m), ctypes.byref(t),
+                ctypes.byref(need), fws.data_ptr(), bws.data_ptr(), grads.data_ptr(), out.data_ptr(),
+                tr._one.data_ptr(), losses.data_ptr(), main_stream, side_stream, int(side_stream is not None)),
+                "rwk_model_train_pass")
+        tr.tail.head_folds += k if fold else 0
+        tr.tail.done = False                          # every step of the pass carried its own update
+        self._grads_to_params()
+        tr.loss = losses[k - 1]
+        return k, losses
+
     def _tail(self, lib, shape):
         tail, o = self.trainer.tail, self.trainer.opt
         t = self.tail_struct
@@ -340,17 +467,7 @@ class TrainStep:
             grads = self._room(2, plan.grad_floats, torch.float32, dev)
             out = self._room(3, n_graphs * m.nc, torch.float32, dev)
             loss = torch.empty((), dtype=torch.float32, device=dev)
-            mods, own = model._modules, model._parameters
-            fc, bn, fc1, fc2 = (mods[k]._parameters for k in ("fc", "bn", "fc1", "fc2"))
-            m.adj_hidden, m.features_hidden = own["adj_hidden"].data_ptr(), own["features_hidden"].data_ptr()
-            m.fc_w, m.fc_b = fc["weight"].data_ptr(), fc["bias"].data_ptr()
-            m.bn_w, m.bn_b = bn["weight"].data_ptr(), bn["bias"].data_ptr()
-            m.w1, m.b1 = fc1["weight"].data_ptr(), fc1["bias"].data_ptr()
-            m.w2, m.b2 = fc2["weight"].data_ptr(), fc2["bias"].data_ptr()
-            buf = mods["bn"]._buffers
-            m.running_mean, m.running_var = buf["running_mean"].data_ptr(), buf["running_var"].data_ptr()
-            m.num_batches_tracked = _lib.ptr(buf["num_batches_tracked"])
-            m.rng_state = model._buffers["_rng_state"].data_ptr() if m.drop_p > 0.0 else None
+            self._point_at_model(m, model)
             fold = plan.train_step == 1
             t = self._tail(lib, "head" if fold else "plain")
             _lib.check(lib.rwk_model_train_step(ctypes.byref(m), ctypes.byref(plan), ctypes.byref(t), fws.data_ptr(),
@@ -358,14 +475,5 @@ class TrainStep:
                                                 loss.data_ptr(), grads.data_ptr(), _lib.current_stream(dev)),
                        "rwk_model_train_step")
         tr.tail.after_launch(fold)
-        # the parameters' gradients: the flat bucket the last launch filled, as zero_grad / backward would leave them
-        views = self.flat_views
-        if views is None or views[0] is not tr.bucket.flat:
-            flat, off, vs = tr.bucket.flat, 0, []
-            for p in tr.bucket.params:
-                vs.append(flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
-            views = self.flat_views = (flat, vs)
-        for p, v in zip(tr.bucket.params, views[1]):
-            p.grad = v
+        self._grads_to_params()
         return loss

@@ -313,3 +313,138 @@ extern "C" int rwk_model_train_step(const rwk_model_step_t *m, const rwk_model_p
         tail->beta2, tail->eps, tail->weight_decay, tail->step_counters, tail->corr_slot, head_part, plan->head_blocks,
         plan->head_grad_floats, d_loss, head_grads, loss_part, loss, m->n_graphs, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// A whole pass over batches that are assembled right before their step (the loop of main.py:103-106 over batches
+// that are never resident twice): per batch the lean rwk_batch_build on the side stream into one of `depth` slots,
+// one batch ahead of the step that reads it, and rwk_model_train_step on the main stream - the calls and the
+// stream order a caller would make batch by batch, issued from one host call.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+void fill_step(rwk_model_step_t *m, const rwk_pass_dataset_t *ds, const rwk_pass_batch_t &bt, const rwk_pass_slot_t &sl) {
+    const bool unit = ds->unit_values != 0;
+    const bool compact = bt.fits16 && sl.col16 != nullptr;
+    m->n = bt.n; m->f = ds->n_feat; m->nnz = bt.nnz; m->n_graphs = bt.b; m->max_graph_nodes = bt.max_graph_nodes;
+    m->max_degree = m->max_degree_t = bt.max_degree;
+    m->features = sl.feats;
+    m->crow = m->crow_t = sl.crow;
+    m->col = m->col_t = sl.col;
+    m->val = unit ? nullptr : sl.val;
+    m->col16_t = compact ? sl.col16 : nullptr;
+    m->val_t = (compact && unit) ? nullptr : sl.val;      // a lean assembly leaves that value array unwritten
+    m->unit_values_t = unit ? 1 : 0;
+    m->long_threshold_t = bt.long_threshold;
+    m->seg_ptr = sl.seg_ptr; m->gid = sl.gid; m->counts_f32 = sl.counts_f32;
+}
+
+bool pass_serves(const rwk_pass_batch_t &bt) { return bt.b >= 2 && bt.n > 0 && bt.nnz > 0 && bt.max_degree <= 64; }
+
+int build_lean(const rwk_pass_dataset_t *ds, const int64_t *tables, const rwk_pass_batch_t &bt,
+               const rwk_pass_slot_t &sl, rwk_stream_t stream) {
+    const bool unit = ds->unit_values != 0;
+    const bool compact = bt.fits16 && sl.col16 != nullptr;
+    return rwk_batch_build(ds->row_ptr, ds->col, ds->val, ds->features, ds->n_feat, ds->y, tables + bt.table_off, bt.b,
+                           bt.n, bt.nnz, nullptr, nullptr, nullptr, ds->n_feat ? sl.feats : nullptr, nullptr, sl.y,
+                           sl.crow, sl.col, (compact && unit) ? nullptr : sl.val, compact ? sl.col16 : nullptr, sl.gid,
+                           sl.seg_ptr, nullptr, sl.counts_f32, stream);
+}
+
+}  // namespace
+
+extern "C" int rwk_model_train_pass_plan(const rwk_pass_dataset_t *ds, const rwk_pass_batch_t *batches,
+                                         int64_t n_batches, const rwk_pass_slot_t *slots, int64_t depth,
+                                         const rwk_model_step_t *model, rwk_pass_need_t *need) {
+    if (!ds || !batches || !slots || !model || !need) return RWK_E_NULL;
+    if (n_batches < 0 || depth < 1) return RWK_E_SIZE;
+    rwk_pass_need_t nd = {};
+    for (int64_t t = 0; t < n_batches; ++t) {
+        if (!pass_serves(batches[t])) break;
+        rwk_model_step_t m = *model;
+        fill_step(&m, ds, batches[t], slots[t % depth]);
+        rwk_model_plan_t pl;
+        if (rwk_model_plan(&m, &pl) != RWK_OK || !pl.train_step) break;
+        if (t == 0) nd.train_step = pl.train_step;
+        else if (pl.train_step != nd.train_step) break;    // the last launch changes shape: the caller's business
+        if (pl.forward_bytes > nd.forward_bytes) nd.forward_bytes = pl.forward_bytes;
+        if (pl.backward_bytes > nd.backward_bytes) nd.backward_bytes = pl.backward_bytes;
+        if (pl.grad_floats > nd.grad_floats) nd.grad_floats = pl.grad_floats;
+        if (m.n_graphs * m.nc > nd.out_floats) nd.out_floats = m.n_graphs * m.nc;
+        nd.served = t + 1;
+    }
+    *need = nd;
+    return RWK_OK;
+}
+
+extern "C" int rwk_model_train_pass(const rwk_pass_dataset_t *ds, const int64_t *tables, const rwk_pass_batch_t *batches,
+                                    int64_t n_batches, const rwk_pass_slot_t *slots, int64_t depth,
+                                    const rwk_model_step_t *model, const rwk_train_tail_t *tail,
+                                    const rwk_pass_need_t *room, void *forward_ws, void *backward_ws, float *grads,
+                                    float *out, const float *d_loss, float *losses, rwk_stream_t main_,
+                                    rwk_stream_t side_, int use_side) {
+    if (!ds || !tables || !batches || !slots || !model || !tail || !room || !forward_ws || !backward_ws || !grads ||
+        !out || !d_loss || !losses)
+        return RWK_E_NULL;
+    if (n_batches <= 0 || depth < 1 || depth > 8) return RWK_E_SIZE;
+    hipStream_t main = (hipStream_t)main_, side = (hipStream_t)side_;
+    hipEvent_t ready[8] = {}, done[8] = {}, start = nullptr;
+    bool done_set[8] = {};
+    int rc = RWK_OK;
+    auto hip = [&](hipError_t e) { if (e != hipSuccess && rc == RWK_OK) rc = (int)e; return e == hipSuccess; };
+    if (use_side) {
+        // the side stream starts behind everything queued on the main stream (the previous pass read the slots)
+        if (!hip(hipEventCreateWithFlags(&start, hipEventDisableTiming))) return rc;
+        for (int64_t k = 0; k < depth && rc == RWK_OK; ++k) {
+            hip(hipEventCreateWithFlags(&ready[k], hipEventDisableTiming));
+            hip(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
+        }
+        if (rc == RWK_OK) hip(hipEventRecord(start, main));
+        if (rc == RWK_OK) hip(hipStreamWaitEvent(side, start, 0));
+    }
+    auto prepare = [&](int64_t t) {
+        const int64_t k = t % depth;
+        if (use_side) {
+            if (done_set[k] && !hip(hipStreamWaitEvent(side, done[k], 0))) return;
+            const int r = build_lean(ds, tables, batches[t], slots[k], side_);
+            if (r) { if (rc == RWK_OK) rc = r; return; }
+            hip(hipEventRecord(ready[k], side));
+        } else {
+            const int r = build_lean(ds, tables, batches[t], slots[k], main_);
+            if (r && rc == RWK_OK) rc = r;
+        }
+    };
+    if (rc == RWK_OK && use_side) prepare(0);
+    for (int64_t t = 0; t < n_batches && rc == RWK_OK; ++t) {
+        const int64_t k = t % depth;
+        if (use_side) {
+            if (t + 1 < n_batches) prepare(t + 1);
+            if (rc != RWK_OK) break;
+            if (!hip(hipStreamWaitEvent(main, ready[k], 0))) break;
+        } else {
+            prepare(t);
+            if (rc != RWK_OK) break;
+        }
+        rwk_model_step_t m = *model;
+        fill_step(&m, ds, batches[t], slots[k]);
+        rwk_model_plan_t pl;
+        int r = pass_serves(batches[t]) ? rwk_model_plan(&m, &pl) : RWK_E_UNSUPPORTED;
+        if (r == RWK_OK && (pl.train_step != room->train_step || pl.forward_bytes > room->forward_bytes ||
+                            pl.backward_bytes > room->backward_bytes || pl.grad_floats > room->grad_floats ||
+                            m.n_graphs * m.nc > room->out_floats))
+            r = RWK_E_SIZE;
+        if (r == RWK_OK)
+            r = rwk_model_train_step(&m, &pl, tail, forward_ws, backward_ws, slots[k].y, d_loss, out, losses + t, grads,
+                                     main_);
+        if (r) { rc = r; break; }
+        if (use_side && hip(hipEventRecord(done[k], main))) done_set[k] = true;
+    }
+    if (use_side) {
+        // (an event may be destroyed while work that waits on it is queued: its resources go when that work is done)
+        for (int64_t k = 0; k < depth; ++k) {
+            if (ready[k]) (void)hipEventDestroy(ready[k]);
+            if (done[k]) (void)hipEventDestroy(done[k]);
+        }
+        if (start) (void)hipEventDestroy(start);
+    }
+    return rc;
+}

@@ -302,10 +302,23 @@ class DeviceDataset:
 
 class BatchPlan:
     """Offset tables of a sequence of batches on the device and their host-side shapes (``DeviceDataset.plan``)."""
-    __slots__ = ("tables", "metas")
+    __slots__ = ("tables", "metas", "_pass_batches")
 
     def __init__(self, tables, metas):
         self.tables, self.metas = tables, metas
+        self._pass_batches = None
+
+    def pass_batches(self, struct):
+        """The shapes as an array of ``rwk_pass_batch_t`` (``struct``: its ctypes mirror), made once per plan."""
+        if self._pass_batches is None:
+            from .structure import spmm_schedule
+            arr = (struct * len(self.metas))()
+            for c, (b, n, nnz, max_degree, fits16, off, _, _, max_graph) in zip(arr, self.metas):
+                c.b, c.n, c.nnz, c.max_graph_nodes, c.table_off = b, n, nnz, max_graph, off
+                c.max_degree, c.fits16 = max_degree, int(fits16)
+                c.long_threshold = int(spmm_schedule(n, nnz, max_degree)[1] or 0)
+            self._pass_batches = arr
+        return self._pass_batches
 
     def __len__(self):
         return len(self.metas)

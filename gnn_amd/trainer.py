@@ -491,24 +491,50 @@ class StreamTrainer(Trainer):
         """One training step per entry of ``id_lists`` (lists of graph ids of the data set), in order.  Returns the
         per-batch loss tensors (read them after the pass)."""
         main = torch.cuda.current_stream(self.dataset.device)
-        depth = len(self.slots)
         losses = []
         if not len(id_lists):
             return losses
         plan = self.dataset.plan(id_lists)       # shapes on the host, offset tables in one upload for the whole pass
-        if self.build_stream is not None:
-            self.build_stream.wait_stream(main)
-        side = self.build_stream is not None
         if self._train_step is None and self.tail is not None:
             from .composite import TrainStep
             self._train_step = TrainStep(self)
         # the whole step as one library call on the slot's buffers (no tensors per batch) where that applies
         raw = self._train_step is not None and self.world == 1 and \
             self._train_step.slots_supported(self.model, self.dataset)
-        nxt = self._prepare(plan, 0, 0, raw)
-        for t in range(len(id_lists)):
+        from . import composite
+        n, t = len(id_lists), 0
+        while t < n:
+            if not (raw and composite.ONE_CALL_PASS):
+                self._run_range(plan, t, n, raw, main, losses, keep_losses)
+                break
+            # every step of the pass (and the assembly in front of it) from ONE library call
+            side = self.build_stream
+            self.loss = None
+            k, ls = self._train_step.run_pass_slots(self.model, self.dataset, self.slots, plan, t, main.cuda_stream,
+                                                    side.cuda_stream if side is not None else None)
+            if k:
+                self.raw_steps += k
+                self.slot_free = [None] * len(self.slots)    # the next assembly waits for the whole launch stream
+                if keep_losses:
+                    losses.extend(ls.unbind(0))
+                t += k
+            if t < n:
+                # a batch the pass call does not serve (or a change of the last launch's shape): the per-batch way
+                self._run_range(plan, t, t + 1, raw, main, losses, keep_losses)
+                t += 1
+        self.pass_losses = losses
+        return losses
+
+    def _run_range(self, plan, t_begin: int, t_end: int, raw: bool, main, losses, keep_losses: bool):
+        """Batches ``t_begin .. t_end - 1`` of the plan, one step each, launched batch by batch."""
+        depth = len(self.slots)
+        if self.build_stream is not None:
+            self.build_stream.wait_stream(main)
+        side = self.build_stream is not None
+        nxt = self._prepare(plan, t_begin, t_begin % depth, raw)
+        for t in range(t_begin, t_end):
             batch, ready = nxt
-            if side and t + 1 < len(id_lists):
+            if side and t + 1 < t_end:
                 nxt = self._prepare(plan, t + 1, (t + 1) % depth, raw)
             if ready is not None:
                 main.wait_event(ready)
@@ -533,7 +559,7 @@ class StreamTrainer(Trainer):
                 done = torch.cuda.Event()
                 done.record(main)
                 self.slot_free[t % depth] = done
-            elif t + 1 < len(id_lists):
+            elif t + 1 < t_end:
                 # same stream: the next assembly is ordered behind this step by the stream itself
                 nxt = self._prepare(plan, t + 1, (t + 1) % depth, raw)
             if keep_losses:

@@ -740,6 +740,62 @@ int rwk_model_train_step(const rwk_model_step_t *m, const rwk_model_plan_t *plan
                          void *forward_ws, void *backward_ws, const int64_t *labels, const float *d_loss, float *out,
                          float *loss, float *grads, rwk_stream_t stream);
 
+/* A whole pass of training steps over batches that are assembled right before their step, in ONE host call: the
+ * loop of rwgnn2/main.py:103-106 (`for i in range(n_train_batches): train(...)`) for a data set too large to keep
+ * its batches resident (utils.py:47-85 builds them all up front).  Per batch: rwk_batch_build without the arrays only
+ * tensors are made of (COO list, int64 graph ids and sizes; the value array too when the batch is unweighted with
+ * compact columns) into slot t % depth, on `side` one batch ahead of the step that reads it (use_side != 0; the side
+ * stream first waits for everything queued on `main`, a slot's next assembly for the step that last read it), or on
+ * `main` in front of its step (use_side == 0); then rwk_model_train_step on `main` with the loss of batch t at
+ * losses[t].  The same launches in the same stream order as those calls made batch by batch: the same bits.
+ *   ds:      the device-resident data set (rwk_batch_build's ds_* arguments); unit_values: every stored value 1.0f
+ *   tables:  the offset tables of all batches, batch t's (4, b+1) table at tables + batches[t].table_off
+ *   batches: host-side shapes; max_degree = longest row of the batch, fits16 = every graph has at most 32512 nodes,
+ *            long_threshold = the packed SpMM's long-row cut for this batch (0: none)
+ *   model:   hyper-parameters, parameter, running-statistics and generator-state pointers (the batch fields are
+ *            filled in per batch from `batches` and `slots`); the data set's adjacency must be symmetric
+ * rwk_model_train_pass_plan runs no launch: need->served = the leading batches the pass serves (it stops at the
+ * first batch rwk_model_plan refuses or whose plan->train_step differs from the first batch's - the caller steps that
+ * one its own way and may call again behind it), and the largest workspaces among them.  rwk_model_train_pass takes
+ * exactly that many batches and workspaces of at least those sizes (`room` = the plan's result; RWK_E_SIZE when a
+ * batch needs more). */
+typedef struct rwk_pass_dataset_t {
+    const int64_t *row_ptr;
+    const int32_t *col;
+    const float *val, *features;
+    int64_t n_feat;
+    const int64_t *y;
+    int32_t unit_values, reserved;
+} rwk_pass_dataset_t;
+
+typedef struct rwk_pass_slot_t {
+    float *feats;
+    int64_t *y;
+    int32_t *crow, *col;
+    float *val;
+    int16_t *col16;                                          /* may be NULL */
+    int32_t *gid, *seg_ptr;
+    float *counts_f32;
+} rwk_pass_slot_t;
+
+typedef struct rwk_pass_batch_t {
+    int64_t b, n, nnz, max_graph_nodes, table_off;
+    int32_t max_degree, fits16, long_threshold, reserved;
+} rwk_pass_batch_t;
+
+typedef struct rwk_pass_need_t {
+    int64_t served, train_step, forward_bytes, backward_bytes, grad_floats, out_floats;
+} rwk_pass_need_t;
+
+int rwk_model_train_pass_plan(const rwk_pass_dataset_t *ds, const rwk_pass_batch_t *batches, int64_t n_batches,
+                              const rwk_pass_slot_t *slots, int64_t depth, const rwk_model_step_t *model,
+                              rwk_pass_need_t *need);
+int rwk_model_train_pass(const rwk_pass_dataset_t *ds, const int64_t *tables, const rwk_pass_batch_t *batches,
+                         int64_t n_batches, const rwk_pass_slot_t *slots, int64_t depth,
+                         const rwk_model_step_t *model, const rwk_train_tail_t *tail, const rwk_pass_need_t *room,
+                         void *forward_ws, void *backward_ws, float *grads, float *out, const float *d_loss,
+                         float *losses, rwk_stream_t main, rwk_stream_t side, int use_side);
+
 /* Test hook: writes the keep-mask exactly as the fused kernels draw it, one byte per element,
  * shape (L, H, S, N), for the {seed, offset} in rng. */
 int rwk_dropout_mask(const uint64_t *rng, int64_t n, int64_t h, int64_t s, int64_t max_step,

@@ -184,3 +184,60 @@ def test_streamed_pass_equals_batches_stepped_one_by_one(shape):
                  (st.opt.exp_avg_sq, one.opt.exp_avg_sq), (st.model.bn.running_mean, one.model.bn.running_mean),
                  (st.model.bn.running_var, one.model.bn.running_var), (st.model._rng_state, one.model._rng_state)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("side_stream", [True, False])
+def test_pass_as_one_library_call_equals_one_call_per_batch(side_stream, monkeypatch):
+    """``rwk_model_train_pass`` (every assembly and step of a pass from one host call) against one
+    ``rwk_model_train_step`` call per batch: same losses, parameters, moments, statistics and generator state, bit for
+    bit - with a ragged batch, a batch the pass call does not serve in the middle (a graph too large for the
+    per-graph forward launch: that batch goes through the tensors, the pass call resumes behind it), and a second pass
+    over the reused slots."""
+    dev = _dev()
+    from gnn_amd import RW_NN, composite
+    from gnn_amd.data import DeviceDataset
+    from gnn_amd.synth import random_batch
+    from gnn_amd.trainer import StreamTrainer
+    whole = random_batch(320, 20, 60, 3.0, seed=21)
+    n0 = whole.n_nodes
+    big = 6000                                            # a ring: symmetric, two entries per row
+    ring = np.arange(big)
+    rows = np.concatenate([whole.indices[0], np.repeat(ring, 2) + n0])
+    nb = np.stack([(ring - 1) % big, (ring + 1) % big], axis=1)
+    nb.sort(axis=1)
+    cols = np.concatenate([whole.indices[1], nb.reshape(-1) + n0])
+    n_all = n0 + big
+    row_ptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n_all))]).astype(np.int64)
+    node_ptr = np.concatenate([[0], np.cumsum(np.concatenate([whole.sizes, [big]]))]).astype(np.int64)
+    feats = np.concatenate([whole.features, np.ones((big, 1), np.float32)]).astype(np.float32)
+    y = np.concatenate([whole.y, [1]]).astype(np.int64)
+    ds = DeviceDataset.from_arrays(node_ptr, row_ptr, cols.astype(np.int32), np.ones(cols.size, np.float32), feats, y,
+                                   dev)
+    assert ds.symmetric
+    order = np.random.default_rng(5).permutation(320)
+    id_lists = [order[i:i + 64] for i in range(0, 320, 64)]
+    id_lists[1] = id_lists[1][:23]                       # ragged
+    id_lists[2] = np.concatenate([id_lists[2][:40], [320]])   # holds the ring
+    shapes = [ds.batch_shape(ids) for ids in id_lists]
+
+    def run(one_call_pass):
+        monkeypatch.setattr(composite, "ONE_CALL_PASS", one_call_pass)
+        torch.manual_seed(0)
+        m = RW_NN(1, 2, 16, 5, 4, 32, False, 2, 0.2, dev).to(dev).train()
+        m.seed_dropout(78)
+        st = StreamTrainer(m, ds, 64, max(s[0] for s in shapes), max(s[1] for s in shapes), depth=3,
+                           side_stream=side_stream)
+        losses = st.run_pass(id_lists)
+        losses += st.run_pass(id_lists[::-1])
+        st.run_pass(id_lists, keep_losses=False)
+        torch.cuda.synchronize()
+        assert st.raw_steps == 12                         # all but the ring's batch, three passes
+        state = [st.opt.flat_param, st.opt.exp_avg, st.opt.exp_avg_sq, st.model.bn.running_mean,
+                 st.model.bn.running_var, st.model._rng_state, st.opt.bucket.flat, st.loss.detach().reshape(1)]
+        return [float(v) for v in losses], [t.clone() for t in state], [p.grad.clone() for p in m.parameters()]
+
+    la, sa, ga = run(True)
+    lb, sb, gb = run(False)
+    assert la == lb and all(np.isfinite(v) for v in la)
+    for a, b in zip(sa + ga, sb + gb):
+        assert torch.equal(a, b)
