@@ -160,14 +160,30 @@ __device__ inline int64_t graph_of_node(const int64_t *__restrict__ start, int64
     return lo;
 }
 
-// The graphs of the nodes v0 .. v1 (of one workgroup) form a range g0 .. g1: two lanes find its ends in the table,
-// the workgroup copies that slice of the node offsets to LDS, and every thread then searches its own node there
-// (a thread-private search of the whole table is twelve dependent trips to the L2 at 4096 graphs).
+// The graphs of the nodes v0 .. v1 (of one workgroup) form a range g0 .. g1: the first wavefront finds its ends in
+// the table - lanes 0-31 for v0, lanes 32-63 for v1, each half probing 32 evenly spaced entries per round and
+// keeping the interval behind the last entry <= v (three rounds for 4096 graphs; a two-way search by one lane made
+// twelve dependent trips to the L2, half of what the whole launch took) - the workgroup copies that slice of the
+// node offsets to LDS, and every thread then searches its own node there.
 constexpr int kSliceMax = 512;
 
 __device__ inline int64_t graph_of_node_block(const int64_t *__restrict__ new_start, int64_t b, int64_t v0, int64_t v1,
                                               int64_t v, bool active, int64_t *slice, int64_t *ends) {
-    if (threadIdx.x < 2) ends[threadIdx.x] = graph_of_node(new_start, 0, b, threadIdx.x == 0 ? v0 : v1);
+    if (threadIdx.x < 64) {
+        const int half = threadIdx.x >> 5, l = threadIdx.x & 31;
+        const int64_t want = half ? v1 : v0;
+        int64_t lo = 0, hi = b;                              // new_start[lo] <= want < new_start[hi]
+        while (hi - lo > 1) {                                // both halves loop until both are done (ballot below)
+            const int64_t step = (hi - lo + 31) / 32;
+            const int64_t p = lo + l * step;
+            const bool ok = p < hi && new_start[p < hi ? p : lo] <= want;      // a prefix of the lanes (lane 0 always)
+            const unsigned long long m = __ballot(ok);
+            const int cnt = __popc((unsigned)(half ? (m >> 32) : m));
+            lo += (int64_t)(cnt - 1) * step;
+            hi = lo + step < hi ? lo + step : hi;
+        }
+        if (l == 0) ends[half] = lo;
+    }
     __syncthreads();
     const int64_t g0 = ends[0], g1 = ends[1];
     const int64_t len = g1 - g0 + 1;
@@ -243,17 +259,32 @@ __global__ void __launch_bounds__(kBlock) batch_build_kernel(const BatchBuildArg
     int32_t *__restrict__ col = a.col;
     float *__restrict__ val = a.val;
     int16_t *__restrict__ col16 = a.col16;
-    for (int64_t e = beg; e < end; ++e, ++o) {
-        const int64_t c = (int64_t)ds_col[e] + delta;
-        const float w = ds_val[e];
-        if (coo_rows) {
-            coo_rows[o] = t;
-            coo_cols[o] = c;
-            coo_vals[o] = w;
+    // four entries of the row per pass, their loads requested together (an entry past the row's end is read at the
+    // pass's first index and not stored): one trip to memory per pass instead of one per entry
+    const bool want_val = coo_vals != nullptr || val != nullptr;
+    for (int64_t e = beg; e < end; e += 4, o += 4) {
+        int32_t cc[4];
+        float ww[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t eu = e + u < end ? e + u : e;
+            cc[u] = ds_col[eu];
+            ww[u] = want_val ? ds_val[eu] : 1.0f;
         }
-        if (col) col[o] = (int32_t)c;
-        if (val) val[o] = w;
-        if (col16) col16[o] = (int16_t)(c - base);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (e + u < end) {
+                const int64_t c = (int64_t)cc[u] + delta;
+                if (coo_rows) {
+                    coo_rows[o + u] = t;
+                    coo_cols[o + u] = c;
+                    coo_vals[o + u] = ww[u];
+                }
+                if (col) col[o + u] = (int32_t)c;
+                if (val) val[o + u] = ww[u];
+                if (col16) col16[o + u] = (int16_t)(c - base);
+            }
+        }
     }
 }
 
