@@ -388,7 +388,7 @@ class StreamBench:
     """A pool of distinct batches of a configuration as one device-resident data set, streamed batch by batch."""
 
     def __init__(self, config, hp, dev, pool_batches, seed, optimizer="flat", world=1, sync_before_all_reduce=False,
-                 side_stream=True):
+                 side_stream=None):
         from gnn_amd.data import DeviceDataset
         from gnn_amd.synth import config_batch
         from gnn_amd.trainer import StreamTrainer
@@ -415,10 +415,11 @@ class StreamBench:
 
     def describe(self):
         return ("pool of %d distinct batches x %d graphs (%d nodes) resident as one data set; every batch assembled "
-                "inside the timed region (one upload per pass + one launch per batch on a side stream, structure "
+                "inside the timed region (one upload per pass + one launch per batch %s, structure "
                 "included), steps launched eagerly%s" % (
                     len(self.id_lists), self.per_batch, self.nodes,
-                    ", each as one library call on the slot's buffers" if self.tr.raw_steps else ""))
+                    "on a side stream" if self.tr._side is not None else "on the step's stream",
+                    ", a whole pass as one library call on the slots' buffers" if self.tr.raw_steps else ""))
 
 
 def stream_extra(config, dev, pool_batches=31, steps=62, warmup=31):

@@ -456,13 +456,20 @@ class StreamTrainer(Trainer):
     batches one by one: the parameters after a pass are the same bits."""
 
     def __init__(self, model, dataset, max_graphs: int, max_nodes: int, max_nnz: int, depth: int = 3,
-                 side_stream: bool = True, **kw):
+                 side_stream=None, **kw):
         if kw.get("world", 1) != 1 and kw.get("capture_collective"):
             raise ValueError("a streamed step is launched eagerly: nothing to capture the collective in")
         self.dataset = dataset
         self.slots = dataset.make_slots(depth, max_graphs, max_nodes, max_nnz)
-        # side_stream=False: the assembly is launched on the step's own stream, in front of the step
-        self.build_stream = torch.cuda.Stream(device=dataset.device) if side_stream else None
+        # side_stream=True: every assembly on a side stream, one batch ahead; False: on the step's own stream, in
+        # front of the step; None: chosen per pass - the side stream where a step has long kernels for the assembly
+        # to hide under (measured on stream_h64: 1.00 against 1.06 ms per step), the step's own stream where the step
+        # is a chain of short launches that an assembly sharing the chip slows by as much as it takes itself, and
+        # the cross-stream waits come on top (the one-call steps at hidden_dim <= 4; proteins1024: 0.104 against
+        # 0.110 ms per step)
+        self.side_stream = side_stream
+        self.build_stream = torch.cuda.Stream(device=dataset.device) if side_stream is not False else None
+        self._side = self.build_stream          # the current pass's choice
         self.slot_free = [None] * depth         # event: the step that last read slot k has been queued and run
         first = dataset.batch(list(range(min(2, dataset.n_graphs))))
         super().__init__(model, first, **kw)
@@ -475,7 +482,7 @@ class StreamTrainer(Trainer):
         None)."""
         from . import _lib
         ds = self.dataset
-        side = self.build_stream
+        side = self._side
         if side is not None and self.slot_free[k] is not None:
             side.wait_event(self.slot_free[k])
         stream = side.cuda_stream if side is not None else _lib.current_stream(ds.device)
@@ -502,13 +509,14 @@ class StreamTrainer(Trainer):
         raw = self._train_step is not None and self.world == 1 and \
             self._train_step.slots_supported(self.model, self.dataset)
         from . import composite
+        self._side = self.build_stream if (self.side_stream or (self.side_stream is None and not raw)) else None
         n, t = len(id_lists), 0
         while t < n:
             if not (raw and composite.ONE_CALL_PASS):
                 self._run_range(plan, t, n, raw, main, losses, keep_losses)
                 break
             # every step of the pass (and the assembly in front of it) from ONE library call
-            side = self.build_stream
+            side = self._side
             self.loss = None
             k, ls = self._train_step.run_pass_slots(self.model, self.dataset, self.slots, plan, t, main.cuda_stream,
                                                     side.cuda_stream if side is not None else None)
@@ -528,9 +536,11 @@ class StreamTrainer(Trainer):
     def _run_range(self, plan, t_begin: int, t_end: int, raw: bool, main, losses, keep_losses: bool):
         """Batches ``t_begin .. t_end - 1`` of the plan, one step each, launched batch by batch."""
         depth = len(self.slots)
-        if self.build_stream is not None:
-            self.build_stream.wait_stream(main)
-        side = self.build_stream is not None
+        if self._side is not None:
+            self._side.wait_stream(main)
+        else:
+            self.slot_free = [None] * depth      # (events of an earlier pass on the side stream: nothing waits there now)
+        side = self._side is not None
         nxt = self._prepare(plan, t_begin, t_begin % depth, raw)
         for t in range(t_begin, t_end):
             batch, ready = nxt

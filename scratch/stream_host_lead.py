@@ -1,5 +1,5 @@
 """Where a streamed pass spends its host time: per pass the host duration of run_pass (launches only), the wait in the
-synchronize behind it, and the host time of DeviceDataset.plan alone.  python scratch/stream_host_lead.py [config]"""
+synchronize behind it, and the host time of DeviceDataset.plan alone.  python scratch/stream_host_lead.py [config] [serial]"""
 import sys
 import time
 
@@ -12,7 +12,9 @@ from gnn_amd.synth import CONFIGS  # noqa: E402
 config = sys.argv[1] if len(sys.argv) > 1 else "stream_h64"
 dev = torch.device("cuda:0")
 hp = dict(CONFIGS[config]["hp"])
-sb = bench.StreamBench(config, hp, dev, 31, seed=4321)
+side = {"serial": False, "side": True}.get(sys.argv[2] if len(sys.argv) > 2 else "", None)      # "serial": the assembly on the step's own stream
+sb = bench.StreamBench(config, hp, dev, 31, seed=4321, side_stream=side)
+print("assembly on", {True: "a side stream", False: "the launch stream", None: "the stream the trainer picks"}[side])
 sb.run(31)
 torch.cuda.synchronize()
 for p in range(4):

@@ -186,7 +186,7 @@ def test_streamed_pass_equals_batches_stepped_one_by_one(shape):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("side_stream", [True, False])
+@pytest.mark.parametrize("side_stream", [True, False, None])
 def test_pass_as_one_library_call_equals_one_call_per_batch(side_stream, monkeypatch):
     """``rwk_model_train_pass`` (every assembly and step of a pass from one host call) against one
     ``rwk_model_train_step`` call per batch: same losses, parameters, moments, statistics and generator state, bit for
