@@ -128,6 +128,42 @@ def test_layer_forward_backward(name, gram, dev, monkeypatch):
 
 
 @pytest.mark.parametrize("name", CASES)
+def test_layer_element_by_element(name, dev):
+    """The same comparison element by element (the checks above are norm-wise): |got - truth| <= 1e-5 |truth| +
+    1e-6 max|truth| against the float64 oracle for every element of K; for the gradients the elements outside that
+    band are counted and held to twice the count of the reference's own float32 result plus one in a thousand (where
+    a sum over the nodes cancels, no float32 summation order keeps every element inside: on the wide case 1.0 % of
+    the reference's features_hidden gradient is outside, 1.5 % of ours; every other case and tensor stays within
+    the reference's own count plus one in a thousand)."""
+    c = GoldenCase(name)
+    m = _model_for(c, dev)
+    adj, feats, gi, _ = c.torch_inputs(dev)
+    feats = feats.clone().requires_grad_(True)
+    k = m.rw_features(adj, feats, gi)
+    csr = (c["csr_crow"], c["csr_col"], c["csr_val"])
+    x0 = _x0(c)
+    k_ref = O.rw_kernel_forward(csr, x0, c.params["adj_hidden"], c.params["features_hidden"],
+                                c["graph_indicator"], c.hp["max_step"], c.hp["normalize"])
+
+    def outside(got, truth):
+        got, truth = np.asarray(got, np.float64), np.asarray(truth, np.float64)
+        return int((np.abs(got - truth) > 1e-5 * np.abs(truth) + 1e-6 * np.abs(truth).max()).sum())
+
+    assert outside(k.detach().cpu().numpy(), k_ref) == 0
+    k.backward(torch.from_numpy(c["dk"]).to(dev))
+    d_x0, d_adj, d_feat = O.rw_kernel_backward(csr, x0, c.params["adj_hidden"], c.params["features_hidden"],
+                                               c["graph_indicator"], c.hp["max_step"], c["dk"], c.hp["normalize"])
+    d_pre = d_x0 * x0 * (1 - x0)
+    pairs = {"features_hidden": (m.features_hidden.grad, d_feat),
+             "features": (feats.grad, d_pre @ c.params["fc.weight"].astype(np.float64))}
+    if c.hp["max_step"] > 1:
+        pairs["adj_hidden"] = (m.adj_hidden.grad, d_adj)
+    for key, (got, truth) in pairs.items():
+        ours, theirs = outside(got.cpu().numpy(), truth), outside(c.grads[key], truth)
+        assert ours <= 2 * theirs + truth.size // 1000, (key, ours, theirs, truth.size)
+
+
+@pytest.mark.parametrize("name", CASES)
 def test_full_model_against_reference(name, dev):
     """Whole forward + cross-entropy backward against the reference's stored outputs.  Gradients behind
     train-mode batch-norm over 3-6 graphs amplify float32 rounding (the reference itself is up to 3.5e-2
