@@ -120,6 +120,8 @@ SIGNATURES = {
     "rwk_x_chain_lds": (_I64, [_I64, _I64, _I64]),
     "rwk_x_chain_hidden_forward": (c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _I64,
                                            _I64, _P, _P, _P, _P, _P]),
+    "rwk_x_chain_hidden_forward_gather": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _I64, _I64,
+                                                  _P, _P, _P, _P, _P]),
     "rwk_graph_chain_forward_lds": (_I64, [_I64, _I64, _I64]),
     "rwk_graph_chain_forward": (c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _I64,
                                         _I64, _P, _P, _P, _P, _P]),

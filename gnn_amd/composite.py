@@ -9,6 +9,7 @@ one node, two calls and four allocations (the two workspaces, the output, the gr
 from __future__ import annotations
 
 import ctypes
+import os
 from ctypes import c_float, c_int32, c_int64, c_void_p
 
 import torch
@@ -88,6 +89,14 @@ class PassNeed(ctypes.Structure):
     _fields_ = [("served", c_int64), ("train_step", c_int64), ("forward_bytes", c_int64),
                 ("backward_bytes", c_int64), ("grad_floats", c_int64), ("out_floats", c_int64)]
 
+
+#: where ``rwk_model_train_pass`` runs the assembly (include/rwk.h)
+PASS_SAME_STREAM, PASS_SIDE_STREAM, PASS_IN_FORWARD = 0, 1, 2
+
+#: the pass call of ``StreamTrainer(side_stream=None)`` lets the forward's first launch assemble the batch
+#: (``rwk_x_chain_hidden_forward_gather``); False keeps the assembly launch in front of each step (tests and
+#: measurements compare the two; RWK_ASSEMBLE_IN_FORWARD=0 in the environment does the same)
+ASSEMBLE_IN_FORWARD = os.environ.get("RWK_ASSEMBLE_IN_FORWARD", "1") != "0"
 
 #: ``StreamTrainer`` issues the steps of a pass through ``rwk_model_train_pass`` (one library call for all of them);
 #: False keeps one ``rwk_model_train_step`` call per batch (tests compare the two)
@@ -354,9 +363,11 @@ class TrainStep:
         for p, v in zip(tr.bucket.params, views[1]):
             p.grad = v
 
-    def run_pass_slots(self, model, dataset, slots, plan, t0: int, main_stream: int, side_stream):
+    def run_pass_slots(self, model, dataset, slots, plan, t0: int, main_stream: int, side_stream,
+                       in_forward: bool = False):
         """The steps of batches ``t0, t0 + 1, ...`` of ``plan``, each assembled into slot ``t % len(slots)`` right
-        before it (``side_stream``: a raw handle, or None for the assembly on the launch stream), as ONE library call
+        before it (``side_stream``: a raw handle, or None for the assembly on the launch stream - or, with
+        ``in_forward``, inside the step's first launch: ``RWK_PASS_IN_FORWARD`` of include/rwk.h), as ONE library call
         (``rwk_model_train_pass``).  Returns (k, losses): the number of batches stepped - the call stops in front of a
         batch it does not serve, 0 when that is batch ``t0`` - and their losses as one tensor of k elements."""
         lib = _lib.load()
@@ -415,7 +426,8 @@ class TrainStep:
             _lib.check(lib.rwk_model_train_pass(
                 ctypes.byref(ds), plan.tables.data_ptr(), first, k, cs, depth, ctypes.byref(m), ctypes.byref(t),
                 ctypes.byref(need), fws.data_ptr(), bws.data_ptr(), grads.data_ptr(), out.data_ptr(),
-                tr._one.data_ptr(), losses.data_ptr(), main_stream, side_stream, int(side_stream is not None)),
+                tr._one.data_ptr(), losses.data_ptr(), main_stream, side_stream,
+                PASS_SIDE_STREAM if side_stream is not None else (PASS_IN_FORWARD if in_forward else PASS_SAME_STREAM)),
                 "rwk_model_train_pass")
         tr.tail.head_folds += k if fold else 0
         tr.tail.done = False                          # every step of the pass carried its own update

@@ -321,6 +321,11 @@ struct XChainArgs {
     float *ah, *z;
     unsigned long long *rng_state, *rng_used;
     int cols_cap;                      // 16-bit column entries the launch's LDS has room for (0: none)
+    // has_gather: the batch is not assembled yet.  The workgroup of batch graph g reads the graph's rows from the
+    // device-resident data set (feat, crow = its 64-bit row pointers, col = its columns; unweighted) and leaves the
+    // batch's structure behind for the launches that follow - what rwk_batch_build would have written beforehand.
+    rwk_x_chain_gather_t gather;
+    int has_gather;
 };
 
 __global__ void __launch_bounds__(kBlock) x_chain_hidden_kernel(const XChainArgs a) {
@@ -345,16 +350,47 @@ __global__ void __launch_bounds__(kBlock) x_chain_hidden_kernel(const XChainArgs
         const int per_xcd = a.n_graphs / 8;
         if (g < per_xcd * 8) g = (((int)blockIdx.x) % 8) * per_xcd + g / 8;
     }
-    const int p0 = a.seg_ptr[g], ng = a.seg_ptr[g + 1] - p0;
+    const rwk_x_chain_gather_t *gt = &a.gather;
+    const bool gather = a.has_gather != 0;
+    // gather: p0 = the graph's first node in the batch, q0 = in the data set; its entries start at eb in the batch
+    int p0, ng;
+    long long q0 = 0;
+    int eb = 0;
+    if (gather) {
+        const long long *__restrict__ tb = reinterpret_cast<const long long *>(gt->table);
+        const long long b1 = (long long)a.n_graphs + 1;
+        const long long s0 = tb[g], s1 = tb[g + 1];
+        q0 = tb[b1 + g];
+        eb = (int)tb[2 * b1 + g];
+        p0 = (int)s0;
+        ng = (int)(s1 - s0);
+        if (tid == 0) {
+            gt->seg_ptr[g] = p0;
+            gt->counts_f32[g] = (float)ng;
+            gt->y[g] = gt->ds_y[tb[3 * b1 + g]];
+            if (g == a.n_graphs - 1) gt->seg_ptr[a.n_graphs] = p0 + ng;
+        }
+    } else {
+        p0 = a.seg_ptr[g];
+        ng = a.seg_ptr[g + 1] - p0;
+    }
+    const float *__restrict__ featp = gather ? gt->ds_feat + (size_t)q0 * a.f : a.feat + (size_t)p0 * a.f;
+    const long long *__restrict__ rp64 = gather ? reinterpret_cast<const long long *>(gt->ds_row_ptr) + q0 : nullptr;
     int e_beg[2] = {0, 0}, e_end[2] = {0, 0};
+    long long r_beg[2] = {0, 0}, r_end[2] = {0, 0}, r_first = 0, r_last = 0;
     float f_first[2] = {0.f, 0.f};             // the first feature of the thread's first two nodes, requested with the
 #pragma unroll                                 // row pointers (in the loop below each cost a trip of its own)
     for (int r = 0; r < 2; ++r) {
         const int local = tid + r * kBlock;
-        if (local < ng) f_first[r] = a.feat[(size_t)(p0 + local) * a.f];
+        if (local < ng) f_first[r] = featp[(size_t)local * a.f];
         if (local < ng && a.steps > 1) {
-            e_beg[r] = a.crow[p0 + local];
-            e_end[r] = a.crow[p0 + local + 1];
+            if (gather) {
+                r_beg[r] = rp64[local];
+                r_end[r] = rp64[local + 1];
+            } else {
+                e_beg[r] = a.crow[p0 + local];
+                e_end[r] = a.crow[p0 + local + 1];
+            }
         }
     }
     // The stored entries of the graph's rows are one contiguous range: with its two ends (requested here, with the row
@@ -363,12 +399,32 @@ __global__ void __launch_bounds__(kBlock) x_chain_hidden_kernel(const XChainArgs
     // dependent trips per step (four entries a trip, and a wavefront waits for its longest row).  Unweighted graphs
     // below 65536 nodes whose entries fit the reserved space; others read memory as before.
     int ge0 = 0, ge1 = 0;
-    if (a.steps > 1 && a.val == nullptr) {
+    if (gather) {
+        if (a.steps > 1 && ng > 0) {
+            r_first = rp64[0];
+            r_last = rp64[ng];
+        }
+    } else if (a.steps > 1 && a.val == nullptr) {
         ge0 = a.crow[p0];
         ge1 = a.crow[p0 + ng];
     }
     for (int i = tid; i < 4 * a.f + 4; i += kBlock) fcs[i] = i < 4 * a.f ? a.fc_w[i] : a.fc_b[i - 4 * a.f];
     __syncthreads();
+    // entries are numbered as in the batch from here on; colp[e] is entry e's column, a node number that starts at
+    // `sub` for the graph's first node (the batch's numbering, or the data set's)
+    const int *__restrict__ colp = a.col;
+    long long sub = p0;
+    if (gather) {
+        ge0 = eb;
+        ge1 = eb + (int)(r_last - r_first);
+        colp = gt->ds_col + (r_first - eb);
+        sub = q0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            e_beg[r] = eb + (int)(r_beg[r] - r_first);
+            e_end[r] = eb + (int)(r_end[r] - r_first);
+        }
+    }
     const int n_e = ge1 - ge0;
     const bool cols_in_lds = n_e > 0 && n_e <= a.cols_cap && ng <= 65536;
     int pre_c[kXChainColsPre];
@@ -376,18 +432,19 @@ __global__ void __launch_bounds__(kBlock) x_chain_hidden_kernel(const XChainArgs
 #pragma unroll
         for (int u = 0; u < kXChainColsPre; ++u) {
             const int i = tid + u * kBlock;
-            pre_c[u] = a.col[ge0 + (i < n_e ? i : n_e - 1)];
+            pre_c[u] = colp[ge0 + (i < n_e ? i : n_e - 1)];
         }
     }
     float4 *x0g = reinterpret_cast<float4 *>(a.xs);
     for (int local = tid, r = 0; local < ng; local += kBlock, ++r) {
         const size_t node = (size_t)(p0 + local);
-        const float *frow = a.feat + node * a.f;
+        const float *frow = featp + (size_t)local * a.f;
         float acc[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = fcs[4 * a.f + c];
         for (int k = 0; k < a.f; ++k) {
             const float fv = (k == 0 && r < 2) ? (r == 0 ? f_first[0] : f_first[1]) : frow[k];
+            if (gather) gt->feat[node * a.f + k] = fv;
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[c] = fmaf(fv, fcs[c * a.f + k], acc[c]);
         }
@@ -395,27 +452,47 @@ __global__ void __launch_bounds__(kBlock) x_chain_hidden_kernel(const XChainArgs
                                      1.0f / (1.0f + expf(-acc[2])), 1.0f / (1.0f + expf(-acc[3])));
         xa[local] = v;
         x0g[node] = v;
+        if (gather) gt->gid[node] = g;
     }
     if (cols_in_lds) {
 #pragma unroll
         for (int u = 0; u < kXChainColsPre; ++u) {
             const int i = tid + u * kBlock;
-            if (i < n_e) cols[i] = (unsigned short)(pre_c[u] - p0);
+            if (i < n_e) cols[i] = (unsigned short)(pre_c[u] - sub);
         }
-        for (int i = tid + kXChainColsPre * kBlock; i < n_e; i += kBlock) cols[i] = (unsigned short)(a.col[ge0 + i] - p0);
+        for (int i = tid + kXChainColsPre * kBlock; i < n_e; i += kBlock) cols[i] = (unsigned short)(colp[ge0 + i] - sub);
     }
     __syncthreads();
     for (int i = 1; i < a.steps; ++i) {
         float4 *xg = reinterpret_cast<float4 *>(a.xs) + (size_t)i * a.n;
+        // gather: the first step also writes the rows' pointers and compact columns (rwk_csr_compact's form: the
+        // distance from the first row of the row's 256-row block)
+        const bool emit = gather && i == 1;
         for (int local = tid, r = 0; local < ng; local += kBlock, ++r) {
             const int node = p0 + local;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int e0 = r == 0 ? e_beg[0] : r == 1 ? e_beg[1] : a.crow[node];
-            const int e1 = r == 0 ? e_end[0] : r == 1 ? e_end[1] : a.crow[node + 1];
+            int e0, e1;
+            if (r < 2) {
+                e0 = r == 0 ? e_beg[0] : e_beg[1];
+                e1 = r == 0 ? e_end[0] : e_end[1];
+            } else if (gather) {
+                e0 = eb + (int)(rp64[local] - r_first);
+                e1 = eb + (int)(rp64[local + 1] - r_first);
+            } else {
+                e0 = a.crow[node];
+                e1 = a.crow[node + 1];
+            }
+            const int cbase = p0 - (node & ~255);          // compact column = (column within the graph) + cbase
+            if (emit) {
+                gt->crow[node] = e0;
+                if (node == a.n - 1) gt->crow[a.n] = e1;
+            }
             if (cols_in_lds) {
                 // acc + x is what fmaf(1.0f, x, acc) returns: the same sum in the same (stored) order
                 for (int e = e0 - ge0; e < e1 - ge0; ++e) {
-                    const float4 rr = xa[cols[e]];
+                    const int cl = cols[e];
+                    const float4 rr = xa[cl];
+                    if (emit) gt->col16[ge0 + e] = (short)(cl + cbase);
                     acc.x += rr.x; acc.y += rr.y; acc.z += rr.z; acc.w += rr.w;
                 }
                 xb[local] = acc;
@@ -428,13 +505,14 @@ __global__ void __launch_bounds__(kBlock) x_chain_hidden_kernel(const XChainArgs
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int at = e + u < e1 ? e + u : e1 - 1;
-                    c[u] = a.col[at] - p0;
+                    c[u] = (int)(colp[at] - sub);
                     w[u] = a.val ? a.val[at] : 1.f;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (e + u < e1) {                          // uniform enough: rows of 3.7 entries on average
                         const float4 rr = xa[c[u]];
+                        if (emit) gt->col16[e + u] = (short)(c[u] + cbase);
                         acc.x = fmaf(w[u], rr.x, acc.x);
                         acc.y = fmaf(w[u], rr.y, acc.y);
                         acc.z = fmaf(w[u], rr.z, acc.z);
@@ -459,6 +537,21 @@ inline size_t eval_lds(int64_t h, int64_t s, int64_t l, int64_t max_nodes, int64
     return (size_t)(l * h * s * 4 + h * s * s + l * max_nodes * 4 + kWaves * l * 16 + l * 16 + lh + p + nc +
                     (p > 0 ? 4 * lh + p * lh + p + nc * p + nc : 0) + 4 * 16 + 4) *
            sizeof(float);
+}
+
+int launch_x_chain(XChainArgs a, int64_t bytes, int64_t f, int64_t max_nodes, int64_t n_graphs, int64_t h,
+                   rwk_stream_t stream) {
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)x_chain_hidden_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    const size_t rows = (size_t)(2 * max_nodes * 4 + 4 * f + 4) * sizeof(float);
+    if (rows + x_chain_cols_bytes(max_nodes) <= kLdsBudget) a.cols_cap = (int)(kXChainColsPerNode * max_nodes);
+    hipLaunchKernelGGL(x_chain_hidden_kernel, dim3((unsigned)(n_graphs + h)), dim3(kBlock), (size_t)bytes,
+                       (hipStream_t)stream, a);
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
 }
 
 }  // namespace
@@ -495,22 +588,37 @@ int rwk_x_chain_hidden_forward(const float *features, const float *weight, const
     if (((uintptr_t)xs & 15u) != 0) return RWK_E_ALIGN;
     const int64_t bytes = rwk_x_chain_lds(f, max_nodes, s);
     if (bytes == 0) return RWK_E_UNSUPPORTED;
-    if (bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)x_chain_hidden_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) return (int)e;
-    }
     XChainArgs a{features, (int)f, weight, bias, crow, col, val, seg_ptr, (int)n, (int)n_graphs, (int)max_nodes,
                  (int)max_step, xs, adj_hidden, features_hidden, (int)h, (int)s, ah, z,
-                 (unsigned long long *)rng_state, (unsigned long long *)rng_used, 0};
-    {
-        const size_t rows = (size_t)(2 * max_nodes * 4 + 4 * f + 4) * sizeof(float);
-        if (rows + x_chain_cols_bytes(max_nodes) <= kLdsBudget) a.cols_cap = (int)(kXChainColsPerNode * max_nodes);
-    }
-    hipLaunchKernelGGL(x_chain_hidden_kernel, dim3((unsigned)(n_graphs + h)), dim3(kBlock), (size_t)bytes,
-                       (hipStream_t)stream, a);
-    RWK_LAUNCH_CHECK();
-    return RWK_OK;
+                 (unsigned long long *)rng_state, (unsigned long long *)rng_used, 0, {}, 0};
+    return launch_x_chain(a, bytes, f, max_nodes, n_graphs, h, stream);
+}
+
+int rwk_x_chain_hidden_forward_gather(const rwk_x_chain_gather_t *gather, const float *weight, const float *bias,
+                                      int64_t n, int64_t f, int64_t n_graphs, int64_t max_nodes, int64_t max_step,
+                                      float *xs, const float *adj_hidden, const float *features_hidden, int64_t h,
+                                      int64_t s, float *ah, float *z, uint64_t *rng_state, uint64_t *rng_used,
+                                      rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(gather);
+    RWK_REQUIRE_PTR(weight);
+    RWK_REQUIRE_PTR(bias);
+    RWK_REQUIRE_PTR(xs);
+    RWK_REQUIRE_PTR(features_hidden);
+    RWK_REQUIRE_PTR(ah);
+    RWK_REQUIRE_PTR(z);
+    if (s > 1) RWK_REQUIRE_PTR(adj_hidden);
+    if (!gather->table || !gather->ds_row_ptr || !gather->ds_col || !gather->ds_feat || !gather->ds_y || !gather->feat ||
+        !gather->y || !gather->crow || !gather->col16 || !gather->gid || !gather->seg_ptr || !gather->counts_f32)
+        return RWK_E_NULL;
+    if (n <= 0 || n >= 0x7FFFFFFFll / 4 || n_graphs <= 0 || n_graphs > n || h <= 0 || h > 65535 || max_step < 2)
+        return RWK_E_SIZE;                        // (the first propagation step writes the rows' structure)
+    if (((uintptr_t)xs & 15u) != 0) return RWK_E_ALIGN;
+    const int64_t bytes = rwk_x_chain_lds(f, max_nodes, s);
+    if (bytes == 0) return RWK_E_UNSUPPORTED;
+    XChainArgs a{nullptr, (int)f, weight, bias, nullptr, nullptr, nullptr, nullptr, (int)n, (int)n_graphs,
+                 (int)max_nodes, (int)max_step, xs, adj_hidden, features_hidden, (int)h, (int)s, ah, z,
+                 (unsigned long long *)rng_state, (unsigned long long *)rng_used, 0, *gather, 1};
+    return launch_x_chain(a, bytes, f, max_nodes, n_graphs, h, stream);
 }
 
 int64_t rwk_eval_forward_lds(int64_t d, int64_t h, int64_t s, int64_t max_step, int64_t f, int64_t max_nodes,

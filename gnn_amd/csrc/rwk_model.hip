@@ -207,9 +207,11 @@ extern "C" int rwk_model_backward(const rwk_model_step_t *m, const rwk_model_pla
                                       d_feat, spb, plan->spb_blocks, wb_n, wb, stream);
 }
 
-extern "C" int rwk_model_train_step(const rwk_model_step_t *m, const rwk_model_plan_t *plan, const rwk_train_tail_t *tail,
-                                    void *forward_ws, void *backward_ws, const int64_t *labels, const float *d_loss,
-                                    float *out, float *loss, float *grads, rwk_stream_t stream) {
+// gather: the batch is not assembled yet - the first launch reads the data set and writes the batch's arrays
+static int train_step_impl(const rwk_model_step_t *m, const rwk_model_plan_t *plan, const rwk_train_tail_t *tail,
+                           void *forward_ws, void *backward_ws, const int64_t *labels, const float *d_loss,
+                           float *out, float *loss, float *grads, rwk_stream_t stream,
+                           const rwk_x_chain_gather_t *gather) {
     int rc = check_step(m, plan);
     if (rc) return rc;
     if (!tail || !forward_ws || !backward_ws || !labels || !d_loss || !out || !loss || !grads || !tail->grad_out)
@@ -238,9 +240,15 @@ extern "C" int rwk_model_train_step(const rwk_model_step_t *m, const rwk_model_p
     float *d_adj = grads, *d_feat = grads + m->h * pairs(m->s);
     float *wb = d_feat + m->h * m->s * m->d, *head_grads = wb + wb_n;
     // forward (model.py:32-72) with the loss sums and the tile part of the head's backward (main.py:85)
-    rc = rwk_x_chain_hidden_forward(m->features, m->fc_w, m->fc_b, m->n, m->f, m->crow, m->col, m->val, m->seg_ptr,
-                                    m->n_graphs, m->max_graph_nodes, m->max_step, xs, m->adj_hidden, m->features_hidden,
-                                    m->h, m->s, ah, z, drop ? m->rng_state : nullptr, rng_layer, stream);
+    if (gather)
+        rc = rwk_x_chain_hidden_forward_gather(gather, m->fc_w, m->fc_b, m->n, m->f, m->n_graphs, m->max_graph_nodes,
+                                               m->max_step, xs, m->adj_hidden, m->features_hidden, m->h, m->s, ah, z,
+                                               drop ? m->rng_state : nullptr, rng_layer, stream);
+    else
+        rc = rwk_x_chain_hidden_forward(m->features, m->fc_w, m->fc_b, m->n, m->f, m->crow, m->col, m->val, m->seg_ptr,
+                                        m->n_graphs, m->max_graph_nodes, m->max_step, xs, m->adj_hidden,
+                                        m->features_hidden, m->h, m->s, ah, z, drop ? m->rng_state : nullptr, rng_layer,
+                                        stream);
     if (rc) return rc;
     rc = rwk_fused_forward_bits(xs, z, m->gid, nullptr, m->n, m->d, m->h, m->s, m->max_step, plan->stream_len_f,
                                 m->drop_p, rng_layer, at<float>(forward_ws, of[F_KPART]), nullptr, stream);
@@ -314,6 +322,12 @@ extern "C" int rwk_model_train_step(const rwk_model_step_t *m, const rwk_model_p
         plan->head_grad_floats, d_loss, head_grads, loss_part, loss, m->n_graphs, stream);
 }
 
+extern "C" int rwk_model_train_step(const rwk_model_step_t *m, const rwk_model_plan_t *plan, const rwk_train_tail_t *tail,
+                                    void *forward_ws, void *backward_ws, const int64_t *labels, const float *d_loss,
+                                    float *out, float *loss, float *grads, rwk_stream_t stream) {
+    return train_step_impl(m, plan, tail, forward_ws, backward_ws, labels, d_loss, out, loss, grads, stream, nullptr);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // A whole pass over batches that are assembled right before their step (the loop of main.py:103-106 over batches
 // that are never resident twice): per batch the lean rwk_batch_build on the side stream into one of `depth` slots,
@@ -385,7 +399,9 @@ extern "C" int rwk_model_train_pass(const rwk_pass_dataset_t *ds, const int64_t 
     if (!ds || !tables || !batches || !slots || !model || !tail || !room || !forward_ws || !backward_ws || !grads ||
         !out || !d_loss || !losses)
         return RWK_E_NULL;
-    if (n_batches <= 0 || depth < 1 || depth > 8) return RWK_E_SIZE;
+    if (n_batches <= 0 || depth < 1 || depth > 8 || use_side < 0 || use_side > 2) return RWK_E_SIZE;
+    const bool in_forward = use_side == RWK_PASS_IN_FORWARD;
+    if (in_forward) use_side = RWK_PASS_SAME_STREAM;         // (the batches it does not serve: assembled on `main`)
     hipStream_t main = (hipStream_t)main_, side = (hipStream_t)side_;
     hipEvent_t ready[8] = {}, done[8] = {}, start = nullptr;
     bool done_set[8] = {};
@@ -420,7 +436,12 @@ extern "C" int rwk_model_train_pass(const rwk_pass_dataset_t *ds, const int64_t 
             if (t + 1 < n_batches) prepare(t + 1);
             if (rc != RWK_OK) break;
             if (!hip(hipStreamWaitEvent(main, ready[k], 0))) break;
-        } else {
+        }
+        // the assembly inside the forward's first launch: an unweighted batch with compact columns
+        const rwk_pass_slot_t &sl = slots[k];
+        const bool gather = in_forward && ds->unit_values && batches[t].fits16 && sl.col16 != nullptr &&
+                            ds->n_feat >= 1;
+        if (!use_side && !gather) {
             prepare(t);
             if (rc != RWK_OK) break;
         }
@@ -432,9 +453,12 @@ extern "C" int rwk_model_train_pass(const rwk_pass_dataset_t *ds, const int64_t 
                             pl.backward_bytes > room->backward_bytes || pl.grad_floats > room->grad_floats ||
                             m.n_graphs * m.nc > room->out_floats))
             r = RWK_E_SIZE;
-        if (r == RWK_OK)
-            r = rwk_model_train_step(&m, &pl, tail, forward_ws, backward_ws, slots[k].y, d_loss, out, losses + t, grads,
-                                     main_);
+        if (r == RWK_OK) {
+            const rwk_x_chain_gather_t gt{tables + batches[t].table_off, ds->row_ptr, ds->col, ds->features, ds->y,
+                                          sl.feats, sl.y, sl.crow, sl.col16, sl.gid, sl.seg_ptr, sl.counts_f32};
+            r = train_step_impl(&m, &pl, tail, forward_ws, backward_ws, sl.y, d_loss, out, losses + t, grads, main_,
+                                gather ? &gt : nullptr);
+        }
         if (r) { rc = r; break; }
         if (use_side && hip(hipEventRecord(done[k], main))) done_set[k] = true;
     }

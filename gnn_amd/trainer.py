@@ -466,7 +466,8 @@ class StreamTrainer(Trainer):
         # to hide under (measured on stream_h64: 1.00 against 1.06 ms per step), the step's own stream where the step
         # is a chain of short launches that an assembly sharing the chip slows by as much as it takes itself, and
         # the cross-stream waits come on top (the one-call steps at hidden_dim <= 4; proteins1024: 0.104 against
-        # 0.110 ms per step)
+        # 0.110 ms per step) - and there the pass call has no assembly launch at all where the batch allows it: the
+        # forward's first launch reads the data set itself (rwk.h: RWK_PASS_IN_FORWARD)
         self.side_stream = side_stream
         self.build_stream = torch.cuda.Stream(device=dataset.device) if side_stream is not False else None
         self._side = self.build_stream          # the current pass's choice
@@ -518,8 +519,10 @@ class StreamTrainer(Trainer):
             # every step of the pass (and the assembly in front of it) from ONE library call
             side = self._side
             self.loss = None
-            k, ls = self._train_step.run_pass_slots(self.model, self.dataset, self.slots, plan, t, main.cuda_stream,
-                                                    side.cuda_stream if side is not None else None)
+            k, ls = self._train_step.run_pass_slots(
+                self.model, self.dataset, self.slots, plan, t, main.cuda_stream,
+                side.cuda_stream if side is not None else None,
+                in_forward=self.side_stream is None and composite.ASSEMBLE_IN_FORWARD)
             if k:
                 self.raw_steps += k
                 self.slot_free = [None] * len(self.slots)    # the next assembly waits for the whole launch stream

@@ -581,6 +581,32 @@ int rwk_x_chain_hidden_forward(const float *features, const float *weight, const
                                const float *adj_hidden, const float *features_hidden, int64_t h, int64_t s, float *ah,
                                float *z, uint64_t *rng_state, uint64_t *rng_used, rwk_stream_t stream);
 
+/* The same launch for a batch that is NOT assembled yet (generate_batches' loop body, utils.py:60-83, inside the
+ * forward's first launch): the workgroup of batch graph g reads the graph's feature rows, 64-bit row pointers and
+ * columns from the device-resident data set of rwk_batch_build (unweighted; `table` is that call's (4, b+1) table) and,
+ * besides xs, leaves behind what the launches after it read of the batch: feat (n, f), y (b), crow (n+1), col16
+ * (rwk_csr_compact's form: every graph of the batch at most 32512 nodes), gid, seg_ptr (b+1), counts_f32 - the same
+ * values rwk_batch_build writes into those arrays.  max_step >= 2 (the first propagation step writes the rows'
+ * pointers and columns).  Same xs, ah, z as rwk_batch_build followed by rwk_x_chain_hidden_forward. */
+typedef struct rwk_x_chain_gather_t {
+    const int64_t *table, *ds_row_ptr;
+    const int32_t *ds_col;
+    const float *ds_feat;
+    const int64_t *ds_y;
+    float *feat;
+    int64_t *y;
+    int32_t *crow;
+    int16_t *col16;
+    int32_t *gid, *seg_ptr;
+    float *counts_f32;
+} rwk_x_chain_gather_t;
+
+int rwk_x_chain_hidden_forward_gather(const rwk_x_chain_gather_t *gather, const float *weight, const float *bias,
+                                      int64_t n, int64_t f, int64_t n_graphs, int64_t max_nodes, int64_t max_step,
+                                      float *xs, const float *adj_hidden, const float *features_hidden, int64_t h,
+                                      int64_t s, float *ah, float *z, uint64_t *rng_state, uint64_t *rng_used,
+                                      rwk_stream_t stream);
+
 /* The same chain for LARGE graphs of a block-diagonal batch (thousands of nodes, power-law hubs; rwgnn2/model.py:43,55
  * at hidden_dim 4, at most 16 input features, sorted graph ids): one workgroup of up to 1024 threads per graph with
  * the graph in LDS - 16 bytes per node for the current rows, the row pointers, and the columns as 16-bit node numbers
@@ -744,10 +770,15 @@ int rwk_model_train_step(const rwk_model_step_t *m, const rwk_model_plan_t *plan
  * loop of rwgnn2/main.py:103-106 (`for i in range(n_train_batches): train(...)`) for a data set too large to keep
  * its batches resident (utils.py:47-85 builds them all up front).  Per batch: rwk_batch_build without the arrays only
  * tensors are made of (COO list, int64 graph ids and sizes; the value array too when the batch is unweighted with
- * compact columns) into slot t % depth, on `side` one batch ahead of the step that reads it (use_side != 0; the side
- * stream first waits for everything queued on `main`, a slot's next assembly for the step that last read it), or on
- * `main` in front of its step (use_side == 0); then rwk_model_train_step on `main` with the loss of batch t at
- * losses[t].  The same launches in the same stream order as those calls made batch by batch: the same bits.
+ * compact columns) into slot t % depth; then rwk_model_train_step on `main` with the loss of batch t at losses[t].
+ * Where the assembly runs (use_side):
+ *   RWK_PASS_SAME_STREAM  on `main`, in front of its step;
+ *   RWK_PASS_SIDE_STREAM  on `side`, one batch ahead of the step that reads it (the side stream first waits for
+ *                         everything queued on `main`, a slot's next assembly for the step that last read it);
+ *   RWK_PASS_IN_FORWARD   inside the step's first launch (rwk_x_chain_hidden_forward_gather: no assembly launch at
+ *                         all) for the batches that allow it - an unweighted data set, compact columns - and on
+ *                         `main` in front of the step for the others.
+ * The same values in the same arrays as those calls made batch by batch: the same bits.
  *   ds:      the device-resident data set (rwk_batch_build's ds_* arguments); unit_values: every stored value 1.0f
  *   tables:  the offset tables of all batches, batch t's (4, b+1) table at tables + batches[t].table_off
  *   batches: host-side shapes; max_degree = longest row of the batch, fits16 = every graph has at most 32512 nodes,
@@ -759,6 +790,10 @@ int rwk_model_train_step(const rwk_model_step_t *m, const rwk_model_plan_t *plan
  * one its own way and may call again behind it), and the largest workspaces among them.  rwk_model_train_pass takes
  * exactly that many batches and workspaces of at least those sizes (`room` = the plan's result; RWK_E_SIZE when a
  * batch needs more). */
+#define RWK_PASS_SAME_STREAM 0
+#define RWK_PASS_SIDE_STREAM 1
+#define RWK_PASS_IN_FORWARD 2
+
 typedef struct rwk_pass_dataset_t {
     const int64_t *row_ptr;
     const int32_t *col;

@@ -13,6 +13,9 @@ config = sys.argv[1] if len(sys.argv) > 1 else "stream_h64"
 dev = torch.device("cuda:0")
 hp = dict(CONFIGS[config]["hp"])
 side = {"serial": False, "side": True}.get(sys.argv[2] if len(sys.argv) > 2 else "", None)      # "serial": the assembly on the step's own stream
+if len(sys.argv) > 2 and sys.argv[2] == "auto_launch":       # the assembly launch in front of every step
+    import gnn_amd.composite
+    gnn_amd.composite.ASSEMBLE_IN_FORWARD = False
 sb = bench.StreamBench(config, hp, dev, 31, seed=4321, side_stream=side)
 print("assembly on", {True: "a side stream", False: "the launch stream", None: "the stream the trainer picks"}[side])
 sb.run(31)
