@@ -241,3 +241,81 @@ def test_pass_as_one_library_call_equals_one_call_per_batch(side_stream, monkeyp
     assert la == lb and all(np.isfinite(v) for v in la)
     for a, b in zip(sa + ga, sb + gb):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n_feat,steps", [(None, 2), (3, 4), (15, 3)])
+def test_forward_launch_that_assembles_the_batch_itself(n_feat, steps):
+    """``rwk_x_chain_hidden_forward_gather`` (the forward's first launch reading the graphs from the data set) against
+    ``rwk_batch_build`` followed by ``rwk_x_chain_hidden_forward``: the same X rows and hidden-graph outputs, and the
+    same feature rows, labels, row pointers, compact columns, graph ids, offsets and sizes - bit for bit; with a ragged
+    batch in data-set order and one in a shuffled order, single-node graphs and a graph of more than 512 nodes (rows
+    beyond a thread's first two) among them."""
+    import ctypes
+    dev = _dev()
+    from gnn_amd import _lib
+    from gnn_amd.data import DeviceDataset
+    from gnn_amd.synth import random_batch
+    kw = {} if n_feat is None else {"n_feat": n_feat}
+    whole = random_batch(96, 1, 90, 3.0, seed=31, **kw)
+    big = random_batch(2, 600, 700, 3.5, seed=32, **kw)
+    rows = np.concatenate([whole.indices[0], big.indices[0] + whole.n_nodes])
+    cols = np.concatenate([whole.indices[1], big.indices[1] + whole.n_nodes]).astype(np.int32)
+    n_all = whole.n_nodes + big.n_nodes
+    row_ptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n_all))]).astype(np.int64)
+    node_ptr = np.concatenate([[0], np.cumsum(np.concatenate([whole.sizes, big.sizes]))]).astype(np.int64)
+    feats = np.concatenate([whole.features, big.features]).astype(np.float32)
+    y = np.concatenate([whole.y, big.y]).astype(np.int64)
+    ds = DeviceDataset.from_arrays(node_ptr, row_ptr, cols, np.ones(cols.size, np.float32), feats, y, dev)
+    assert ds.symmetric and ds.unit_values
+    f = ds.n_feat
+    lib = _lib.load()
+    stream = _lib.current_stream(dev)
+    h, s = 6, 5
+    torch.manual_seed(3)
+    w = torch.randn(4, f, device=dev)
+    b = torch.randn(4, device=dev)
+    adj_hidden = torch.randn(h, s * (s - 1) // 2, device=dev)
+    feat_hidden = torch.randn(h, s, 4, device=dev)
+
+    class Gather(ctypes.Structure):
+        _fields_ = [(k, ctypes.c_void_p) for k in ("table", "ds_row_ptr", "ds_col", "ds_feat", "ds_y", "feat", "y",
+                                                   "crow", "col16", "gid", "seg_ptr", "counts_f32")]
+
+    order = np.random.default_rng(7).permutation(98)
+    for ids in (np.arange(5, 70), order[:41], np.array([97, 3, 96, 11])):
+        plan = ds.plan([ids])
+        adj, fe, gi, yy = ds.batch_planned(plan, 0)
+        from gnn_amd.structure import get_structure
+        st = get_structure(adj, gi)
+        bsz, n, nnz, _, fits16, off, _, _, max_graph = plan.metas[0]
+        assert fits16 and st.csr.col16 is not None
+        xs_a = torch.empty(steps, n, 4, device=dev)
+        ah_a, z_a = torch.empty(h, s, s, device=dev), torch.empty(steps, h, s, 4, device=dev)
+        _lib.check(lib.rwk_x_chain_hidden_forward(
+            fe.data_ptr(), w.data_ptr(), b.data_ptr(), n, f, st.csr.crow.data_ptr(), st.csr.col.data_ptr(), None,
+            st.seg_ptr.data_ptr(), bsz, max_graph, steps, xs_a.data_ptr(), adj_hidden.data_ptr(),
+            feat_hidden.data_ptr(), h, s, ah_a.data_ptr(), z_a.data_ptr(), None, None, stream), "x_chain")
+        out = {"feat": torch.full((n, f), -1.0, device=dev), "y": torch.full((bsz,), -1, dtype=torch.int64, device=dev),
+               "crow": torch.full((n + 1,), -1, dtype=torch.int32, device=dev),
+               "col16": torch.full((nnz,), -1, dtype=torch.int16, device=dev),
+               "gid": torch.full((n,), -1, dtype=torch.int32, device=dev),
+               "seg_ptr": torch.full((bsz + 1,), -1, dtype=torch.int32, device=dev),
+               "counts_f32": torch.full((bsz,), -1.0, device=dev)}
+        g = Gather()
+        g.table = plan.tables.data_ptr() + 8 * off
+        g.ds_row_ptr, g.ds_col = ds.row_ptr.data_ptr(), ds.col.data_ptr()
+        g.ds_feat, g.ds_y = ds.features.data_ptr(), ds.y.data_ptr()
+        for k, t in out.items():
+            setattr(g, k, t.data_ptr())
+        xs_b = torch.empty(steps, n, 4, device=dev)
+        ah_b, z_b = torch.empty(h, s, s, device=dev), torch.empty(steps, h, s, 4, device=dev)
+        _lib.check(lib.rwk_x_chain_hidden_forward_gather(
+            ctypes.byref(g), w.data_ptr(), b.data_ptr(), n, f, bsz, max_graph, steps, xs_b.data_ptr(),
+            adj_hidden.data_ptr(), feat_hidden.data_ptr(), h, s, ah_b.data_ptr(), z_b.data_ptr(), None, None, stream),
+            "x_chain gather")
+        torch.cuda.synchronize()
+        assert torch.equal(xs_a, xs_b) and torch.equal(ah_a, ah_b) and torch.equal(z_a, z_b)
+        want = {"feat": fe, "y": yy, "crow": st.csr.crow, "col16": st.csr.col16, "gid": st.gid, "seg_ptr": st.seg_ptr,
+                "counts_f32": st.counts_f32}
+        for k in out:
+            assert torch.equal(out[k], want[k].reshape(out[k].shape)), k
