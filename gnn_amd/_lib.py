@@ -117,6 +117,8 @@ SIGNATURES = {
     "rwk_eval_forward_lds": (_I64, [_I64] * 8),
     "rwk_eval_forward": (c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64,
                                  c_int, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
+    "rwk_eval_forward_gather": (c_int, [_P, _P, _P, _P, _I64, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, c_int,
+                                        _P, _P, _P, _P, c_float, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "rwk_x_chain_lds": (_I64, [_I64, _I64, _I64]),
     "rwk_x_chain_hidden_forward": (c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _I64,
                                            _I64, _P, _P, _P, _P, _P]),

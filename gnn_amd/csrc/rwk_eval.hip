@@ -40,6 +40,11 @@ struct EvalArgs {
     const float *w1, *b1, *w2, *b2;
     int p, nc;
     float *k_out, *out;
+    // Not null: the graphs are read from the device-resident data set of rwk_batch_build (feat = its feature rows,
+    // col = its columns, unweighted), graph g of the launch being the entry g of the batch's (4, b+1) offset table;
+    // no batch is assembled.
+    const long long *table, *ds_row_ptr;
+    int n_graphs;
 };
 
 __device__ inline float pick4(const float4 &v, int a) { return a == 0 ? v.x : a == 1 ? v.y : a == 2 ? v.z : v.w; }
@@ -72,7 +77,19 @@ __global__ void __launch_bounds__(kBlock) eval_forward_kernel(const EvalArgs a) 
     float *fcs = b2s + a.nc;                           // [d * f + d]: projection weights and bias
     const int tid = threadIdx.x;
     const int g = blockIdx.x;
-    const int p0 = a.seg_ptr[g], ng = a.seg_ptr[g + 1] - p0;
+    // p0: the graph's first node in the arrays the rows are read from (the batch's, or the data set's)
+    long long p0;
+    int ng;
+    const bool gather = a.table != nullptr;
+    if (gather) {
+        ng = (int)(a.table[g + 1] - a.table[g]);
+        p0 = a.table[(long long)a.n_graphs + 1 + g];
+    } else {
+        p0 = a.seg_ptr[g];
+        ng = a.seg_ptr[g + 1] - (int)p0;
+    }
+    const long long *__restrict__ rp64 = gather ? a.ds_row_ptr + p0 : nullptr;
+    const int *__restrict__ rp32 = gather ? nullptr : a.crow + p0;
 
     // ---- hidden graphs: Ah = sym(triu(relu(adj_hidden))), Z_i = Ah Z_{i-1}
     const int n_pairs = s * (s - 1) / 2;
@@ -89,8 +106,8 @@ __global__ void __launch_bounds__(kBlock) eval_forward_kernel(const EvalArgs a) 
     for (int r = 0; r < 2; ++r) {
         const int local = tid + r * kBlock;
         if (local < ng) {
-            e_beg[r] = a.crow[p0 + local];
-            e_end[r] = a.crow[p0 + local + 1];
+            e_beg[r] = gather ? (int)rp64[local] : rp32[local];
+            e_end[r] = gather ? (int)rp64[local + 1] : rp32[local + 1];
             if (a.fc_w != nullptr) f_first[r] = a.feat[(size_t)(p0 + local) * a.f];
         }
     }
@@ -165,10 +182,9 @@ __global__ void __launch_bounds__(kBlock) eval_forward_kernel(const EvalArgs a) 
         const float4 *xp = reinterpret_cast<const float4 *>(xs) + (size_t)(i - 1) * a.max_nodes;
         float4 *xn = reinterpret_cast<float4 *>(xs) + (size_t)i * a.max_nodes;
         for (int local = tid, r = 0; local < ng; local += kBlock, ++r) {
-            const int node = p0 + local;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int e0 = r == 0 ? e_beg[0] : r == 1 ? e_beg[1] : a.crow[node];
-            const int e1 = r == 0 ? e_end[0] : r == 1 ? e_end[1] : a.crow[node + 1];
+            const int e0 = r == 0 ? e_beg[0] : r == 1 ? e_beg[1] : (gather ? (int)rp64[local] : rp32[local]);
+            const int e1 = r == 0 ? e_end[0] : r == 1 ? e_end[1] : (gather ? (int)rp64[local + 1] : rp32[local + 1]);
             // four stored entries per trip, their columns (and values) requested together; entries past the row's end
             // enter with weight zero (fmaf(0, r, acc) is acc), so the sum runs in stored order whatever the length
             for (int e = e0; e < e1; e += 4) {
@@ -177,7 +193,7 @@ __global__ void __launch_bounds__(kBlock) eval_forward_kernel(const EvalArgs a) 
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int at = e + u < e1 ? e + u : e1 - 1;
-                    c[u] = a.col[at] - p0;
+                    c[u] = a.col[at] - (int)p0;
                     w[u] = a.val ? a.val[at] : 1.f;
                     if (e + u >= e1) w[u] = 0.f;
                 }
@@ -236,7 +252,7 @@ __global__ void __launch_bounds__(kBlock) eval_forward_kernel(const EvalArgs a) 
     __syncthreads();
     // ---- K row of the graph
     const int lh = LT * h;
-    const float cnt = a.normalize ? a.counts_f32[g] : 1.f;
+    const float cnt = a.normalize ? (gather ? (float)ng : a.counts_f32[g]) : 1.f;
     for (int idx = tid; idx < lh; idx += kBlock) {
         const int i = idx / h, hh = idx - i * h;
         const float *c = cm + i * 16;
@@ -539,6 +555,28 @@ inline size_t eval_lds(int64_t h, int64_t s, int64_t l, int64_t max_nodes, int64
            sizeof(float);
 }
 
+int launch_eval(const EvalArgs &a, int64_t bytes, int64_t n_graphs, int64_t max_step, rwk_stream_t stream) {
+    const dim3 grid((unsigned)n_graphs);
+#define RWK_EVAL(LT)                                                                                          \
+    do {                                                                                                      \
+        if (bytes > 64 * 1024) {                                                                              \
+            hipError_t e = hipFuncSetAttribute((const void *)eval_forward_kernel<LT>,                         \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);      \
+            if (e != hipSuccess) return (int)e;                                                               \
+        }                                                                                                     \
+        hipLaunchKernelGGL(eval_forward_kernel<LT>, grid, dim3(kBlock), (size_t)bytes, (hipStream_t)stream, a); \
+    } while (0)
+    switch (max_step) {
+        case 1: RWK_EVAL(1); break;
+        case 2: RWK_EVAL(2); break;
+        case 3: RWK_EVAL(3); break;
+        default: RWK_EVAL(4); break;
+    }
+#undef RWK_EVAL
+    RWK_LAUNCH_CHECK();
+    return RWK_OK;
+}
+
 int launch_x_chain(XChainArgs a, int64_t bytes, int64_t f, int64_t max_nodes, int64_t n_graphs, int64_t h,
                    rwk_stream_t stream) {
     if (bytes > 64 * 1024) {
@@ -664,26 +702,47 @@ int rwk_eval_forward(const float *feat, int64_t f, const float *fc_w, const floa
     if (bytes == 0) return RWK_E_UNSUPPORTED;
     EvalArgs a{feat, (int)f, fc_w, fc_b, adj_hidden, feat_hidden, crow, col, val, seg_ptr, counts_f32, (int)n, (int)d,
                (int)h, (int)s, normalize, (int)max_nodes, bn_w, bn_b, running_mean, running_var, eps, w1, b1, w2, b2,
-               (int)p, (int)nc, k_out, out};
-    const dim3 grid((unsigned)n_graphs);
-#define RWK_EVAL(LT)                                                                                          \
-    do {                                                                                                      \
-        if (bytes > 64 * 1024) {                                                                              \
-            hipError_t e = hipFuncSetAttribute((const void *)eval_forward_kernel<LT>,                         \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);      \
-            if (e != hipSuccess) return (int)e;                                                               \
-        }                                                                                                     \
-        hipLaunchKernelGGL(eval_forward_kernel<LT>, grid, dim3(kBlock), (size_t)bytes, (hipStream_t)stream, a); \
-    } while (0)
-    switch (max_step) {
-        case 1: RWK_EVAL(1); break;
-        case 2: RWK_EVAL(2); break;
-        case 3: RWK_EVAL(3); break;
-        default: RWK_EVAL(4); break;
+               (int)p, (int)nc, k_out, out, nullptr, nullptr, (int)n_graphs};
+    return launch_eval(a, bytes, n_graphs, max_step, stream);
+}
+
+int rwk_eval_forward_gather(const int64_t *table, const int64_t *ds_row_ptr, const int32_t *ds_col, const float *ds_feat,
+                            int64_t f, const float *fc_w, const float *fc_b, const float *adj_hidden,
+                            const float *feat_hidden, int64_t n_graphs, int64_t max_nodes, int64_t d, int64_t h,
+                            int64_t s, int64_t max_step, int normalize, const float *bn_w, const float *bn_b,
+                            const float *running_mean, const float *running_var, float eps, const float *w1,
+                            const float *b1, const float *w2, const float *b2, int64_t p, int64_t nc, float *k_out,
+                            float *out, rwk_stream_t stream) {
+    RWK_REQUIRE_PTR(table);
+    RWK_REQUIRE_PTR(ds_row_ptr);
+    RWK_REQUIRE_PTR(ds_feat);
+    RWK_REQUIRE_PTR(feat_hidden);
+    RWK_REQUIRE_PTR(fc_w);
+    RWK_REQUIRE_PTR(fc_b);
+    if (s > 1) RWK_REQUIRE_PTR(adj_hidden);
+    if (k_out == nullptr && out == nullptr) return RWK_E_NULL;
+    if (out != nullptr) {
+        RWK_REQUIRE_PTR(bn_w);
+        RWK_REQUIRE_PTR(bn_b);
+        RWK_REQUIRE_PTR(running_mean);
+        RWK_REQUIRE_PTR(running_var);
+        RWK_REQUIRE_PTR(w1);
+        RWK_REQUIRE_PTR(b1);
+        RWK_REQUIRE_PTR(w2);
+        RWK_REQUIRE_PTR(b2);
+        if (p < 1 || nc < 1) return RWK_E_SIZE;
+    } else {
+        p = 0;
+        nc = 0;
     }
-#undef RWK_EVAL
-    RWK_LAUNCH_CHECK();
-    return RWK_OK;
+    if (n_graphs <= 0 || n_graphs >= 0x7FFFFFFFll || max_nodes <= 0) return RWK_E_SIZE;
+    const int64_t bytes = rwk_eval_forward_lds(d, h, s, max_step, f, max_nodes, p, nc);
+    if (bytes == 0) return RWK_E_UNSUPPORTED;
+    EvalArgs a{ds_feat, (int)f, fc_w, fc_b, adj_hidden, feat_hidden, nullptr, ds_col, nullptr, nullptr, nullptr, 0,
+               (int)d, (int)h, (int)s, normalize, (int)max_nodes, bn_w, bn_b, running_mean, running_var, eps, w1, b1,
+               w2, b2, (int)p, (int)nc, k_out, out, reinterpret_cast<const long long *>(table),
+               reinterpret_cast<const long long *>(ds_row_ptr), (int)n_graphs};
+    return launch_eval(a, bytes, n_graphs, max_step, stream);
 }
 
 }  // extern "C"

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["eval_forward_supported", "eval_forward"]
+__all__ = ["eval_forward_supported", "eval_forward", "eval_forward_planned"]
 
 #: False keeps the separate launches in evaluation mode (tests compare the two)
 FUSED_EVAL_FORWARD = True
@@ -107,3 +107,47 @@ class _EvalForward(torch.autograd.Function):
 
 def eval_forward(model, st, features):
     return _EvalForward.apply(model, st, features, *model.parameters())
+
+
+def eval_forward_planned(model, dataset, plan, i: int, out: torch.Tensor = None):
+    """``model.eval()``'s output for batch ``i`` of ``plan`` (``DeviceDataset.plan``: lists of graph ids of a
+    device-resident data set) WITHOUT assembling the batch: one launch whose workgroups read their graphs straight
+    from the data set (``rwk_eval_forward_gather``) - the validation / test loop (``rwgnn2/main.py:110-117,148-151``)
+    for data sets that do not stay resident as batches.  Returns the (graphs, n_classes) log-probabilities (into
+    ``out`` when given), or None when the launch does not serve the model or the batch (a weighted data set, wide
+    features, hidden_dim > 4, a graph too large for the LDS, rows of more than 64 entries): assemble the batch
+    (``dataset.batch_planned``) and call the model then.  No autograd graph is recorded."""
+    if not FUSED_EVAL_FORWARD or model.training or not dataset.unit_values or not 1 <= dataset.n_feat <= 16:
+        return None
+    h, s, d = model.features_hidden.shape
+    bn = model.bn
+    if d > 4 or model.max_step > 4 or model.fc.in_features != dataset.n_feat or not (
+            model.fused_head and bn.affine and bn.track_running_stats and model.fc1.bias is not None
+            and model.fc2.bias is not None and bn.num_features == model.hidden_graphs * model.max_step):
+        return None
+    b, n, nnz, max_degree, _, off, _, _, max_graph = plan.metas[i]
+    if max_graph > MAX_GRAPH_NODES or max_degree > 64:
+        return None
+    lib = _lib.load()
+    p, nc = model.fc1.out_features, model.fc2.out_features
+    if not lib.rwk_eval_forward_lds(d, h, s, model.max_step, dataset.n_feat, max_graph, p, nc):
+        return None
+    dev = dataset.device
+    with _lib.device_guard(dev), torch.no_grad():
+        if out is None:
+            out = torch.empty((b, nc), dtype=torch.float32, device=dev)
+        elif out.shape != (b, nc) or out.dtype is not torch.float32 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float32 tensor of shape (graphs, n_classes)")
+        t = [x.detach().contiguous() for x in (model.fc.weight, model.fc.bias, model.adj_hidden, model.features_hidden,
+                                               bn.weight, bn.bias, model.fc1.weight, model.fc1.bias, model.fc2.weight,
+                                               model.fc2.bias)]
+        fc_w, fc_b, adj_h, feat_h, bn_w, bn_b, w1, b1, w2, b2 = t
+        _lib.check(lib.rwk_eval_forward_gather(
+            plan.tables.data_ptr() + 8 * off, dataset.row_ptr.data_ptr(), _lib.ptr(dataset.col),
+            dataset.features.data_ptr(), dataset.n_feat, fc_w.data_ptr(), fc_b.data_ptr(),
+            _lib.ptr(adj_h) if adj_h.numel() else None, feat_h.data_ptr(), b, max_graph, d, h, s, model.max_step,
+            int(bool(model.normalize)), bn_w.data_ptr(), bn_b.data_ptr(), bn.running_mean.data_ptr(),
+            bn.running_var.data_ptr(), float(bn.eps), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), p, nc,
+            None, out.data_ptr(), _lib.current_stream(dev)), "rwk_eval_forward_gather")
+    out._rwk_plan_tables = plan.tables          # the launch reads them asynchronously
+    return out

@@ -568,6 +568,19 @@ int rwk_eval_forward(const float *feat, int64_t f, const float *fc_w, const floa
                      const float *w1, const float *b1, const float *w2, const float *b2, int64_t p, int64_t nc,
                      float *k_out, float *out, rwk_stream_t stream);
 
+/* The same launch on graphs that were never assembled into a batch (the validation and test loops of
+ * rwgnn2/main.py:110-117,148-151 over a data set that does not stay resident as batches): graph g of the launch is
+ * entry g of `table`, the (4, b+1) offset table of rwk_batch_build, and its feature rows, 64-bit row pointers and
+ * columns are read straight from that call's device-resident data set (unweighted; fc_w, fc_b required).  Nothing
+ * is written but k_out / out: the same values as rwk_batch_build followed by rwk_eval_forward. */
+int rwk_eval_forward_gather(const int64_t *table, const int64_t *ds_row_ptr, const int32_t *ds_col, const float *ds_feat,
+                            int64_t f, const float *fc_w, const float *fc_b, const float *adj_hidden,
+                            const float *feat_hidden, int64_t n_graphs, int64_t max_nodes, int64_t d, int64_t h,
+                            int64_t s, int64_t max_step, int normalize, const float *bn_w, const float *bn_b,
+                            const float *running_mean, const float *running_var, float eps, const float *w1,
+                            const float *b1, const float *w2, const float *b2, int64_t p, int64_t nc, float *k_out,
+                            float *out, rwk_stream_t stream);
+
 /* The node features of every step and the hidden graphs in one launch (model.py:39-43,55-56 at hidden_dim 4 with
  * at most 16 input features), for block-diagonal batches with sorted graph ids: the workgroup of graph g projects
  * its nodes into LDS and gathers each propagation step from there; xs (max_step, n, 4) receives every X_i; the

@@ -319,3 +319,45 @@ def test_forward_launch_that_assembles_the_batch_itself(n_feat, steps):
                 "counts_f32": st.counts_f32}
         for k in out:
             assert torch.equal(out[k], want[k].reshape(out[k].shape)), k
+
+
+@pytest.mark.parametrize("n_feat,steps,normalize", [(None, 2, False), (3, 4, True), (15, 1, False)])
+def test_evaluation_forward_straight_from_the_data_set(n_feat, steps, normalize):
+    """``eval_forward_planned`` (one launch that reads its graphs from the data set, no batch assembled) against the
+    model called in evaluation mode on the assembled batch: the same log-probabilities, bit for bit."""
+    dev = _dev()
+    from gnn_amd import RW_NN
+    from gnn_amd.data import DeviceDataset
+    from gnn_amd.eval import eval_forward_planned
+    from gnn_amd.synth import random_batch
+    kw = {} if n_feat is None else {"n_feat": n_feat}
+    whole = random_batch(96, 1, 90, 3.0, seed=41, **kw)
+    big = random_batch(2, 600, 700, 3.5, seed=42, **kw)
+    rows = np.concatenate([whole.indices[0], big.indices[0] + whole.n_nodes])
+    cols = np.concatenate([whole.indices[1], big.indices[1] + whole.n_nodes]).astype(np.int32)
+    n_all = whole.n_nodes + big.n_nodes
+    row_ptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n_all))]).astype(np.int64)
+    node_ptr = np.concatenate([[0], np.cumsum(np.concatenate([whole.sizes, big.sizes]))]).astype(np.int64)
+    feats = np.concatenate([whole.features, big.features]).astype(np.float32)
+    y = np.concatenate([whole.y, big.y]).astype(np.int64)
+    ds = DeviceDataset.from_arrays(node_ptr, row_ptr, cols, np.ones(cols.size, np.float32), feats, y, dev)
+    torch.manual_seed(5)
+    m = RW_NN(ds.n_feat, steps, 16, 5, 4, 32, normalize, 3, 0.2, dev).to(dev)
+    with torch.no_grad():
+        m.bn.running_mean.uniform_(-0.5, 0.5)
+        m.bn.running_var.uniform_(0.5, 2.0)
+    order = np.random.default_rng(9).permutation(98)
+    id_lists = [np.arange(5, 70), order[:41], np.array([97, 3, 96, 11])]
+    plan = ds.plan(id_lists)
+    m.train()
+    assert eval_forward_planned(m, ds, plan, 0) is None         # training mode: not this launch's business
+    m.eval()
+    for i in range(len(id_lists)):
+        adj, fe, gi, _ = ds.batch_planned(plan, i)
+        with torch.no_grad():
+            want = m(adj, fe, gi)
+        got = eval_forward_planned(m, ds, plan, i)
+        assert got is not None and got.shape == want.shape
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+        assert np.isfinite(got.cpu().numpy()).all()
