@@ -450,6 +450,35 @@ def eager_step_extra(batch_t, hp, dev, steps=200, warmup=50):
                     "library call (rwk_model_train_step), the same eight launches"}
 
 
+def eval_stream_extra(config, dev, pool_batches=31, passes=4):
+    """model.eval()'s forward over the batches of a pool without assembling them: one launch per batch that reads its
+    graphs from the device-resident data set (gnn_amd.eval.eval_forward_planned)."""
+    from gnn_amd.data import DeviceDataset
+    from gnn_amd.eval import eval_forward_planned
+    from gnn_amd.synth import CONFIGS, config_batch
+    hp = dict(CONFIGS[config]["hp"])
+    whole = config_batch(config, seed=4321, scale=pool_batches)
+    per = whole.n_graphs // pool_batches
+    ds = DeviceDataset.from_batch(whole, dev)
+    id_lists = [np.arange(i * per, (i + 1) * per) for i in range(pool_batches)]
+    model = _new_model(hp, dev).eval()
+    plan = ds.plan(id_lists)
+    outs = [torch.empty(per, hp["n_classes"], device=dev) for _ in range(pool_batches)]
+
+    def run(n):
+        for _ in range(n):
+            for i in range(pool_batches):
+                if eval_forward_planned(model, ds, plan, i, outs[i]) is None:
+                    raise RuntimeError("the evaluation launch does not serve this configuration")
+    run(1)
+    elapsed, dev_ms = _timed(run, passes)
+    batches = passes * pool_batches
+    return {"config": config, "batches": batches, "us_per_batch": round(elapsed / batches * 1e6, 2),
+            "device_us_per_batch": round(dev_ms / batches * 1e3, 2), "graphs_per_s": round(per * batches / elapsed, 1),
+            "what": "evaluation-mode forward of %d distinct batches x %d graphs read straight from the resident data "
+                    "set: one launch per batch, no batch assembled" % (pool_batches, per)}
+
+
 def cpu_baseline(batch, hp, n_graphs, budget_s=20.0):
     """Forward + backward (train mode, dropout on) of the PyTorch-CPU port on the first n_graphs graphs."""
     from oracle import rwnn_torch_port as P
@@ -742,8 +771,9 @@ def main():
             try:
                 result["distinct_batches"] = distinct_batches_epoch(args.config, hp, dev, 16)
                 result["stream_h64_stream"] = stream_extra("stream_h64", dev)
-                result["stream_proteins1024"] = stream_extra("proteins1024", dev, steps=124, warmup=31)
+                result["stream_proteins1024"] = stream_extra("proteins1024", dev, steps=372, warmup=93)
                 result["eager_one_call_step"] = eager_step_extra(batch_t, hp, dev)
+                result["eval_from_data_set"] = eval_stream_extra("proteins1024", dev)
             except Exception as exc:                      # the extras never cost the headline
                 result["extras_error"] = "%s: %s" % (type(exc).__name__, str(exc)[:300])
         if not args.no_cpu_baseline and world == 1:
