@@ -536,6 +536,34 @@ class StreamTrainer(Trainer):
         self.pass_losses = losses
         return losses
 
+    def evaluate(self, id_lists):
+        """The model's output (log-probabilities, one tensor per entry of ``id_lists``) for batches of the data set, in
+        the model's current mode - the validation / test loop of ``rwgnn2/main.py:110-117,148-151`` (call
+        ``model.eval()`` first, as the reference does).  In evaluation mode a batch the one-launch forward serves is
+        not assembled at all (``gnn_amd.eval.eval_forward_planned``: its workgroups read the graphs from the data
+        set); any other batch is assembled into a slot and goes through ``model(...)``.  No gradients are recorded."""
+        from .eval import eval_forward_planned
+        outs = []
+        if not len(id_lists):
+            return outs
+        plan = self.dataset.plan(id_lists)
+        main = torch.cuda.current_stream(self.dataset.device)
+        depth = len(self.slots)
+        # every slot may still be read by queued steps or be written on the side stream: both end before this
+        if self.build_stream is not None:
+            main.wait_stream(self.build_stream)
+        used = 0
+        with torch.no_grad():
+            for i in range(len(id_lists)):
+                out = None if self.model.training else eval_forward_planned(self.model, self.dataset, plan, i)
+                if out is None:
+                    batch = self.dataset.batch_planned(plan, i, self.slots[used % depth])
+                    used += 1
+                    out = self.model(batch[0], batch[1], batch[2])
+                outs.append(out)
+        self.slot_free = [None] * depth
+        return outs
+
     def _run_range(self, plan, t_begin: int, t_end: int, raw: bool, main, losses, keep_losses: bool):
         """Batches ``t_begin .. t_end - 1`` of the plan, one step each, launched batch by batch."""
         depth = len(self.slots)

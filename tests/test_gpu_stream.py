@@ -361,3 +361,44 @@ def test_evaluation_forward_straight_from_the_data_set(n_feat, steps, normalize)
         torch.cuda.synchronize()
         assert torch.equal(got, want)
         assert np.isfinite(got.cpu().numpy()).all()
+
+
+def test_stream_trainer_evaluates_batches_of_the_data_set():
+    """``StreamTrainer.evaluate``: outputs equal to the model called on the assembled batches, in evaluation mode
+    (one launch per batch, nothing assembled) and in training mode with dropout off (assembled into the slots), and a
+    training pass still runs after it on the same slots."""
+    dev = _dev()
+    from gnn_amd import RW_NN
+    from gnn_amd.data import DeviceDataset
+    from gnn_amd.synth import random_batch
+    from gnn_amd.trainer import StreamTrainer
+    whole = random_batch(200, 10, 50, 3.0, seed=51)
+    ds = DeviceDataset.from_batch(whole, dev)
+    id_lists = [np.arange(i, i + 40) for i in range(0, 200, 40)]
+    shapes = [ds.batch_shape(ids) for ids in id_lists]
+    torch.manual_seed(0)
+    m = RW_NN(1, 2, 16, 5, 4, 32, False, 2, 0.0, dev).to(dev).train()
+    st = StreamTrainer(m, ds, 40, max(s[0] for s in shapes), max(s[1] for s in shapes), depth=3)
+    st.run_pass(id_lists)
+    for mode in ("eval", "train"):
+        getattr(m, mode)()
+        if mode == "train":
+            running = [m.bn.running_mean.clone(), m.bn.running_var.clone(), m.bn.num_batches_tracked.clone()]
+        outs = st.evaluate(id_lists)
+        if mode == "train":       # the reference calls with a fresh batch norm state each time; compare like with like
+            m.bn.running_mean.copy_(running[0]); m.bn.running_var.copy_(running[1])
+            m.bn.num_batches_tracked.copy_(running[2])
+        assert len(outs) == len(id_lists)
+        for ids, out in zip(id_lists, outs):
+            adj, fe, gi, _ = ds.batch(ids)
+            with torch.no_grad():
+                want = m(adj, fe, gi)
+            torch.cuda.synchronize()
+            assert out.shape == want.shape and not out.requires_grad
+            assert torch.equal(out, want), mode
+            if mode == "train":
+                break             # (each training-mode call moves the running statistics: one batch is enough)
+    m.train()
+    losses = st.run_pass(id_lists)
+    torch.cuda.synchronize()
+    assert all(np.isfinite(float(v)) for v in losses)
