@@ -344,6 +344,8 @@ struct XChainArgs {
     int has_gather;
 };
 
+// GATHER: the instance that reads the data set (XChainArgs::gather); the other one carries none of that code
+template <bool GATHER>
 __global__ void __launch_bounds__(kBlock) x_chain_hidden_kernel(const XChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // the hidden graphs' workgroups come first: dispatched behind a thousand graph workgroups they would start when
@@ -367,7 +369,7 @@ __global__ void __launch_bounds__(kBlock) x_chain_hidden_kernel(const XChainArgs
         if (g < per_xcd * 8) g = (((int)blockIdx.x) % 8) * per_xcd + g / 8;
     }
     const rwk_x_chain_gather_t *gt = &a.gather;
-    const bool gather = a.has_gather != 0;
+    constexpr bool gather = GATHER;
     // gather: p0 = the graph's first node in the batch, q0 = in the data set; its entries start at eb in the batch
     int p0, ng;
     long long q0 = 0;
@@ -579,15 +581,14 @@ int launch_eval(const EvalArgs &a, int64_t bytes, int64_t n_graphs, int64_t max_
 
 int launch_x_chain(XChainArgs a, int64_t bytes, int64_t f, int64_t max_nodes, int64_t n_graphs, int64_t h,
                    rwk_stream_t stream) {
+    auto kern = a.has_gather ? x_chain_hidden_kernel<true> : x_chain_hidden_kernel<false>;
     if (bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)x_chain_hidden_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return (int)e;
     }
     const size_t rows = (size_t)(2 * max_nodes * 4 + 4 * f + 4) * sizeof(float);
     if (rows + x_chain_cols_bytes(max_nodes) <= kLdsBudget) a.cols_cap = (int)(kXChainColsPerNode * max_nodes);
-    hipLaunchKernelGGL(x_chain_hidden_kernel, dim3((unsigned)(n_graphs + h)), dim3(kBlock), (size_t)bytes,
-                       (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_graphs + h)), dim3(kBlock), (size_t)bytes, (hipStream_t)stream, a);
     RWK_LAUNCH_CHECK();
     return RWK_OK;
 }
