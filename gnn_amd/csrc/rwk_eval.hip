@@ -57,7 +57,8 @@ __device__ inline float slot_sum16(float v) {
     return v;
 }
 
-template <int LT>
+// GATHER: the instance that reads the graphs from the data set (EvalArgs::table); the other carries none of that code
+template <int LT, bool GATHER>
 __global__ void __launch_bounds__(kBlock) eval_forward_kernel(const EvalArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int h = a.h, s = a.s, d = a.d;
@@ -80,7 +81,7 @@ __global__ void __launch_bounds__(kBlock) eval_forward_kernel(const EvalArgs a) 
     // p0: the graph's first node in the arrays the rows are read from (the batch's, or the data set's)
     long long p0;
     int ng;
-    const bool gather = a.table != nullptr;
+    constexpr bool gather = GATHER;
     if (gather) {
         ng = (int)(a.table[g + 1] - a.table[g]);
         p0 = a.table[(long long)a.n_graphs + 1 + g];
@@ -561,12 +562,13 @@ int launch_eval(const EvalArgs &a, int64_t bytes, int64_t n_graphs, int64_t max_
     const dim3 grid((unsigned)n_graphs);
 #define RWK_EVAL(LT)                                                                                          \
     do {                                                                                                      \
+        auto kern = a.table != nullptr ? eval_forward_kernel<LT, true> : eval_forward_kernel<LT, false>;      \
         if (bytes > 64 * 1024) {                                                                              \
-            hipError_t e = hipFuncSetAttribute((const void *)eval_forward_kernel<LT>,                         \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);      \
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                               (int)bytes);                                                   \
             if (e != hipSuccess) return (int)e;                                                               \
         }                                                                                                     \
-        hipLaunchKernelGGL(eval_forward_kernel<LT>, grid, dim3(kBlock), (size_t)bytes, (hipStream_t)stream, a); \
+        hipLaunchKernelGGL(kern, grid, dim3(kBlock), (size_t)bytes, (hipStream_t)stream, a);                  \
     } while (0)
     switch (max_step) {
         case 1: RWK_EVAL(1); break;
