@@ -165,3 +165,40 @@ def test_distance_bias_oracle_against_scipy_dijkstra():
             if n > 1:
                 assert np.allclose(pm.sum(1), 1.0)
             assert np.allclose(np.diag(pm), c / n)
+
+
+def test_pass_and_gather_entry_points_reject_bad_arguments_before_any_launch():
+    """The entry points of a streamed pass check their arguments on the host: null pointers and sizes out of range
+    come back as RWK_E_NULL / RWK_E_SIZE without a GPU being touched, and the plan call - host code only - serves
+    nothing when the first batch is outside what the one-call step takes."""
+    import ctypes
+    from gnn_amd import _lib
+    from gnn_amd.composite import ModelStep, PassBatch, PassDataset, PassNeed, PassSlot
+    lib = _lib.load()
+    E_NULL, E_SIZE = -1, -2
+    ds, need, model = PassDataset(), PassNeed(), ModelStep()
+    batches, slots = (PassBatch * 2)(), (PassSlot * 3)()
+    args = [ctypes.byref(ds), batches, 2, slots, 3, ctypes.byref(model), ctypes.byref(need)]
+    assert lib.rwk_model_train_pass_plan(*args) == 0 and need.served == 0        # b = 0: nothing served
+    assert lib.rwk_model_train_pass_plan(None, *args[1:]) == E_NULL
+    assert lib.rwk_model_train_pass_plan(*args[:4], 0, *args[5:]) == E_SIZE      # no slots
+    one = ctypes.c_float()
+    buf = ctypes.create_string_buffer(256)
+    p = ctypes.addressof(buf)
+    tail = ctypes.create_string_buffer(512)
+    good = [ctypes.byref(ds), p, batches, 2, slots, 3, ctypes.byref(model), ctypes.addressof(tail), ctypes.byref(need),
+            p, p, p, p, ctypes.addressof(one), p, None, None, 0]
+    for k in (0, 1, 2, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14):
+        bad = list(good)
+        bad[k] = None
+        assert lib.rwk_model_train_pass(*bad) == E_NULL, k
+    for k, v in ((3, 0), (5, 0), (5, 9), (17, 3), (17, -1)):
+        bad = list(good)
+        bad[k] = v
+        assert lib.rwk_model_train_pass(*bad) == E_SIZE, (k, v)
+    assert lib.rwk_x_chain_hidden_forward_gather(None, p, p, 10, 1, 2, 8, 2, p, p, p, 4, 3, p, p, None, None,
+                                                 None) == E_NULL
+    assert lib.rwk_eval_forward_gather(None, p, p, p, 1, p, p, p, p, 2, 8, 4, 4, 3, 2, 0, p, p, p, p, 1e-5, p, p, p, p,
+                                       8, 2, None, p, None) == E_NULL
+    assert lib.rwk_eval_forward_gather(p, p, p, p, 1, p, p, p, p, 0, 8, 4, 4, 3, 2, 0, p, p, p, p, 1e-5, p, p, p, p,
+                                       8, 2, None, p, None) == E_SIZE
