@@ -770,7 +770,7 @@ def main():
             # what no resident-batch figure covers: batches that change every step
             try:
                 result["distinct_batches"] = distinct_batches_epoch(args.config, hp, dev, 16)
-                result["stream_h64_stream"] = stream_extra("stream_h64", dev)
+                result["stream_h64_stream"] = stream_extra("stream_h64", dev, steps=124, warmup=93)
                 result["stream_proteins1024"] = stream_extra("proteins1024", dev, steps=372, warmup=279)
                 result["eager_one_call_step"] = eager_step_extra(batch_t, hp, dev)
                 result["eval_from_data_set"] = eval_stream_extra("proteins1024", dev)
