@@ -144,3 +144,77 @@ def test_epoch_graph_trains_like_the_step_loop():
                  (eager.opt.exp_avg_sq, graph.opt.exp_avg_sq), (eager.model.bn.running_mean, graph.model.bn.running_mean),
                  (eager.model.bn.running_var, graph.model.bn.running_var), (eager.model._rng_state, graph.model._rng_state)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_evaluation_from_the_data_set_against_the_reference_output():
+    """The reference's own evaluation-mode output for its second MUTAG batch (golden ``mutag_b1_eval``: made by the
+    reference's ``load_data``, ``generate_batches`` and ``RW_NN`` under ``model.eval()``) against the launch that reads
+    the graphs straight from the device-resident data set, no batch assembled: files -> DeviceDataset ->
+    ``eval_forward_planned``; norm-wise 1e-5, and every element within 1e-5 |ref| + 1e-6 max|ref|."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gnn_amd import RW_NN
+    from gnn_amd.data import DeviceDataset, load_data
+    from gnn_amd.eval import eval_forward_planned
+    from _golden import rel_err
+    dev = torch.device("cuda:0")
+    c = GoldenCase("mutag_b1_eval")
+    assert not c.train
+    adj, features, y = load_data("MUTAG", False, root=ROOT)
+    y = np.unique(y, return_inverse=True)[1]
+    ds = DeviceDataset(adj, features, y, dev)
+    hp = c.hp
+    m = RW_NN(hp["input_dim"], hp["max_step"], hp["hidden_graphs"], hp["size_hidden_graphs"], hp["hidden_dim"],
+              hp["penultimate_dim"], bool(hp["normalize"]), hp["n_classes"], hp["dropout"], dev)
+    m.load_state_dict(c.torch_state(), strict=True)
+    m = m.to(dev).eval()
+    plan = ds.plan([np.arange(0, 64), np.arange(64, 128)])
+    out = eval_forward_planned(m, ds, plan, 1)
+    assert out is not None
+    got, ref = out.cpu().numpy().astype(np.float64), c["out"].astype(np.float64)
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < 1e-5
+    assert np.all(np.abs(got - ref) <= 1e-5 * np.abs(ref) + 1e-6 * np.abs(ref).max())
+
+
+@pytest.mark.gpu
+def test_streamed_training_step_against_the_reference_output(monkeypatch):
+    """The reference's own training-mode loss and gradients for its first MUTAG batch (golden ``mutag_b0``) against a
+    streamed step: files -> DeviceDataset -> ``StreamTrainer.run_pass`` - the pass as one library call, the batch
+    assembled inside the forward's first launch.  Loss to 1e-4; gradients to the bound of
+    ``test_full_model_against_reference`` (behind train-mode batch-norm over 64 graphs the reference itself is that far
+    from the float64 truth)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import gnn_amd.function as fn
+    from gnn_amd import RW_NN
+    from gnn_amd.data import DeviceDataset, load_data
+    from gnn_amd.trainer import StreamTrainer
+    from _golden import rel_err
+    from test_gpu_parity import _float64_port_grads
+    monkeypatch.setattr(fn, "GRAM_FAST_PATH", False)     # the golden ran without dropout: keep the stream kernels
+    dev = torch.device("cuda:0")
+    c = GoldenCase("mutag_b0")
+    assert c.train
+    adj, features, y = load_data("MUTAG", False, root=ROOT)
+    y = np.unique(y, return_inverse=True)[1]
+    ds = DeviceDataset(adj, features, y, dev)
+    hp = c.hp
+    m = RW_NN(hp["input_dim"], hp["max_step"], hp["hidden_graphs"], hp["size_hidden_graphs"], hp["hidden_dim"],
+              hp["penultimate_dim"], bool(hp["normalize"]), hp["n_classes"], hp["dropout"], dev)
+    m.load_state_dict(c.torch_state(), strict=True)
+    m = m.to(dev).train()
+    ids = np.arange(0, 64)
+    n, nnz = ds.batch_shape(ids)
+    st = StreamTrainer(m, ds, 64, n, nnz, depth=3)
+    losses = st.run_pass([ids])
+    torch.cuda.synchronize()
+    assert st.raw_steps == 1                              # one library call, no tensors, no assembly launch
+    assert abs(float(losses[0]) - float(c["loss"])) < 1e-4 * max(1.0, abs(float(c["loss"])))
+    truth = _float64_port_grads(c)
+    for name, p in m.named_parameters():
+        got = p.grad.cpu().numpy()
+        ref_own_err = rel_err(c.grads[name], truth[name])
+        tiny = float(np.max(np.abs(got - truth[name]))) < 2e-6
+        assert tiny or rel_err(got, truth[name]) < max(5e-3, 10 * ref_own_err), name
