@@ -218,3 +218,42 @@ def test_streamed_training_step_against_the_reference_output(monkeypatch):
         ref_own_err = rel_err(c.grads[name], truth[name])
         tiny = float(np.max(np.abs(got - truth[name]))) < 2e-6
         assert tiny or rel_err(got, truth[name]) < max(5e-3, 10 * ref_own_err), name
+
+
+@pytest.mark.gpu
+def test_epoch_loop_over_a_streamed_data_set():
+    """The reference's epoch loop (main.py:101-117) on the MUTAG files without resident batches: training passes and
+    validation passes over the same slots, three epochs; the loss falls and the validation outputs are proper
+    log-probabilities."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gnn_amd import RW_NN
+    from gnn_amd.data import DeviceDataset, load_data
+    from gnn_amd.trainer import StreamTrainer
+    dev = torch.device("cuda:0")
+    adj, features, y = load_data("MUTAG", False, root=ROOT)
+    y = np.unique(y, return_inverse=True)[1]
+    ds = DeviceDataset(adj, features, y, dev)
+    order = np.random.default_rng(0).permutation(188)
+    train_ids = [order[i:i + 32] for i in range(0, 160, 32)]
+    val_ids = [order[160:188]]
+    shapes = [ds.batch_shape(ids) for ids in train_ids + val_ids]
+    torch.manual_seed(0)
+    model = RW_NN(ds.n_feat, 2, 16, 5, 4, 32, False, 2, 0.2, dev).to(dev)
+    model.seed_dropout(5)
+    tr = StreamTrainer(model, ds, 32, max(s[0] for s in shapes), max(s[1] for s in shapes), lr=1e-2)
+    first = last = None
+    for epoch in range(3):
+        model.train()
+        losses = tr.run_pass(train_ids)
+        model.eval()
+        outs = tr.evaluate(val_ids)
+        torch.cuda.synchronize()
+        mean = float(torch.stack(losses).mean())
+        first = mean if first is None else first
+        last = mean
+        assert len(outs) == 1 and outs[0].shape == (28, 2)
+        assert torch.allclose(outs[0].exp().sum(1), torch.ones(28, device=dev), atol=1e-5)
+        acc = float((outs[0].argmax(1) == ds.y[torch.as_tensor(val_ids[0], device=dev)]).float().mean())
+        assert 0.0 <= acc <= 1.0
+    assert tr.raw_steps == 15 and np.isfinite(last) and last < first
